@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s (rays x spp) of the cloud radiance estimator on the
+BASELINE.json configuration "512^3 density, 1024x1024, 1024 spp progressive" (configs[2]; the
+driver's N>1 runs are configs[3]: the same job sharded by 8x8-pixel tile over N GPUs with an RCCL
+reduce of the accumulated radiance buffer).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one progressive batch of --spp-per-step subframes of the whole frame: estimator
+kernel + Welford accumulate kernel, plus (N>1) the reduce of the W*H float4 radiance buffer to
+rank 0.  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
+before the timed region and resident in HBM).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--volume", type=int, default=512, help="density texture edge (texels)")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--mode", type=int, default=0, help="0 totalRadiance (Mie multi-scatter + NEE)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--simple-kernel", action="store_true", help="A/B: one thread per pixel, nested loops")
+    return ap.parse_args()
+
+
+def cpu_baseline(tex, ins, width, height, mode, target_s):
+    """The oracle (our CPU port of the reference; the reference has no CPU path) on all host
+    cores, on a bounded sample of the SAME workload: the centred 256x256 window."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import _oracle as O
+    cores = int(O.lib(True).orc_max_threads())
+    orc = O.Oracle(tex, width, height, mode=mode, fast=True, inscatter=ins, threads=cores)
+    x0, y0 = width // 2 - 128, height // 2 - 128
+    win = (max(x0, 0), max(y0, 0), min(x0 + 256, width), min(y0 + 256, height))
+    npix = (win[2] - win[0]) * (win[3] - win[1])
+    t0 = time.perf_counter()
+    orc.render_subframe(1, win)
+    t1 = time.perf_counter() - t0
+    spp = int(min(max(round(target_s / max(t1, 1e-3)), 1), 64))
+    before = orc.counters.as_dict()
+    t0 = time.perf_counter()
+    for sid in range(2, 2 + spp):
+        orc.render_subframe(sid, win)
+    dt = time.perf_counter() - t0
+    after = orc.counters.as_dict()
+    lookups = (after["density_lookups"] + after["inscatter_lookups"]) - (before["density_lookups"] + before["inscatter_lookups"])
+    return {
+        "value": npix * spp / dt / 1e6,
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"centred {win[2]-win[0]}x{win[3]-win[1]} window x {spp} spp of the same volume/camera ({dt:.1f} s)",
+        "lookups_per_s": lookups / dt,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    import deepestscatter_amd as ds
+    from deepestscatter_amd import _lib
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libcloudtrace has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, S = args.width, args.height, args.spp_per_step
+    t_setup = time.perf_counter()
+    tex = ds.make_procedural_cloud(args.volume)
+    flags = _lib.CT_FLAG_SIMPLE_KERNEL if args.simple_kernel else 0
+    tr = ds.CloudTracer(tex, width=W, height=H, mode=args.mode, device=local_rank, shard_index=rank,
+                        shard_count=world, flags=flags)
+    setup_s = time.perf_counter() - t_setup
+
+    merged = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    nbytes = merged.numel() * 4
+
+    def step(first):
+        tr.render_accumulate(first, S)
+        if world > 1:
+            # frame reduce: tiles are disjoint, so SUM merges the per-GPU radiance buffers exactly
+            tr.copy_to_device(_lib.CT_BUF_MEAN, merged.data_ptr(), nbytes)
+            dist.reduce(merged, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nxt = 1
+    for _ in range(args.warmup):
+        step(nxt)
+        nxt += S
+    k0 = tr.counters()
+    r0, a0, l0 = tr.kernel_time()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(nxt)
+        nxt += S
+    fence()
+    elapsed = time.perf_counter() - t0
+    k1 = tr.counters()
+    r1, a1, l1 = tr.kernel_time()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    total_samples = W * H * S * args.steps
+    value = total_samples / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (the estimator), this rank's launches in the timed region
+    dk = {k: k1[k] - k0[k] for k in k1}
+    launches = max(l1 - l0, 1)
+    render_ms = r1 - r0
+    lookups = dk["density_lookups"] + dk["inscatter_lookups"]
+    # algorithmic bytes: 8 B per trilinear lookup (density or shadow volume) + the 16 B float4 result
+    # each sample writes (accumulation's 64 B/pixel/batch belongs to the second, tiny kernel)
+    alg_bytes = 8 * lookups + 16 * dk["paths"]
+    achieved = alg_bytes / (render_ms * 1e-3) / 1e9 if render_ms > 0 else 0.0
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_latest.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": "render_persistent_kernel" if not args.simple_kernel else "render_simple_kernel",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": alg_bytes / launches,
+        "avg_launch_ms": render_ms / launches, "launches": launches,
+        "lookups_per_s": lookups / (render_ms * 1e-3) if render_ms > 0 else 0.0,
+        "lookups_per_sample": lookups / max(dk["paths"], 1),
+        "accumulate_ms_per_launch": (a1 - a0) / launches,
+    }
+
+    out = {
+        "metric": "Msamples/s (rays x spp) at 512^3 vol, 1024^2 frame; HBM GB/s vs roofline",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{args.volume}^3 procedural density, {W}x{H}, progressive, {S} spp per step "
+                        f"(BASELINE.json configs[{2 if world == 1 else 3}]: 1024 spp job = {1024 // max(S,1)} such steps), "
+                        f"mode {('totalRadiance','multipleScatterSunRadiance','singleScatterSunRadiance')[args.mode]} "
+                        "(Mie multi-scatter + NEE), estimator MARCH (reference-faithful), max_depth 2000",
+            "volume": args.volume, "width": W, "height": H, "spp_per_step": S,
+            "parallelism": f"pixel-tile shard x{world}" + (" + RCCL reduce of the radiance buffer" if world > 1 else ""),
+        },
+        "roofline": roofline,
+        "setup_s": setup_s,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ins = tr.inscatter()
+        out["cpu_baseline"] = cpu_baseline(tex, ins, W, H, args.mode, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    tr.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""Builds libcloudtrace.so (HIP, gfx950) in-tree with hipcc.  No cmake, no JIT cache.
+
+    python -m deepestscatter_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored but travels
+to the GPU box with the working tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+ROOT = PKG.parent
+LIB = PKG / "libcloudtrace.so"
+
+SOURCES = ["ct_kernels.hip", "ct_api.cpp", "ct_host.cpp"]
+HEADERS = [CSRC / "ct_device.hpp", CSRC / "ct_internal.hpp", ROOT / "include" / "cloudtrace.h",
+           ROOT / "include" / "ct_fmath.h"]
+
+# -ffp-contract=off is part of the numeric contract (include/ct_fmath.h): results must be
+# bit-identical to the CPU oracle, so no implicit FMA contraction and no fast-math.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+         "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-value"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm; set HIPCC=...)")
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + HEADERS
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), *FLAGS, "-o", str(LIB), *[str(CSRC / s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=str(CSRC))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,270 @@
+"""Thin object wrapper over the C ABI (include/cloudtrace.h): one `CloudTracer` = one CtHandle.
+
+This is plumbing only -- every numeric result comes from libcloudtrace.so (HIP kernels).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CT_BUF_DENSITY, CT_BUF_FRAME, CT_BUF_INSCATTER, CT_BUF_M2, CT_BUF_MEAN, CT_BUF_SCREEN,
+                   CtCounters, CtScene, check)
+
+MIE_FILE = Path(__file__).resolve().parent / "data" / "mie_raw.f32"
+
+# Tasks.cpp:52-65
+LIGHT_DIRECTIONS = {
+    "Front": (-0.586, -0.766, -0.271),
+    "Side": (-0.03, -0.25, 0.8),
+    "Back": (0.586, -0.766, -0.271),
+}
+
+
+def load_mie_raw() -> tuple[np.ndarray, np.ndarray]:
+    """The two 4096-entry Lorenz-Mie tables (data of Mie.cpp:8-8203): (mie, choppedMie)."""
+    raw = np.fromfile(MIE_FILE, dtype="<f4")
+    if raw.size != 8192:
+        raise RuntimeError(f"{MIE_FILE} is corrupt")
+    return np.ascontiguousarray(raw[:4096]), np.ascontiguousarray(raw[4096:])
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def calculate_camera_variables(eye, lookat, up, hfov_deg: float, aspect_ratio: float):
+    """sutil::calculateCameraVariables(..., fov_is_vertical=false), sutil.cpp:501-524."""
+    e, la, u = (np.asarray(v, np.float32) for v in (eye, lookat, up))
+    U, V, W = (np.empty(3, np.float32) for _ in range(3))
+    check(_lib.load().ct_calculate_camera_variables(_p(e), _p(la), _p(u), hfov_deg, aspect_ratio, _p(U), _p(V), _p(W)))
+    return U, V, W
+
+
+def quantize_volume(grid: np.ndarray) -> np.ndarray:
+    """Resources::loadVolumeBuffer's quantiser (Resources.cpp:92-141): float [Z,Y,X] payload ->
+    uint8 [Z+2,Y+2,X+2] texture with a zero border."""
+    grid = np.ascontiguousarray(grid, np.float32)
+    nz, ny, nx = grid.shape
+    pd = np.array([nx, ny, nz], np.uint32)
+    out = np.empty((nz + 2, ny + 2, nx + 2), np.uint8)
+    check(_lib.load().ct_quantize_volume(_p(grid), _p(pd), _p(out)))
+    return out
+
+
+def generate_mipmaps(level0: np.ndarray) -> list[np.ndarray]:
+    """Resources::generateMipmaps (Resources.cpp:169-209): list of uint8 [z,y,x] levels."""
+    level0 = np.ascontiguousarray(level0, np.uint8)
+    nz, ny, nx = level0.shape
+    dims = np.array([nx, ny, nz], np.uint32)
+    L = _lib.load()
+    levels, total = C.c_uint32(0), C.c_size_t(0)
+    offs = (C.c_size_t * 32)()
+    check(L.ct_generate_mipmaps(_p(level0), _p(dims), None, 0, C.byref(levels), C.byref(total), offs))
+    buf = np.empty(total.value, np.uint8)
+    check(L.ct_generate_mipmaps(_p(level0), _p(dims), _p(buf), buf.size, C.byref(levels), C.byref(total), offs))
+    out = []
+    for l in range(levels.value):
+        shape = (max(nz >> l, 1), max(ny >> l, 1), max(nx >> l, 1))
+        n = int(np.prod(shape))
+        out.append(buf[offs[l]:offs[l] + n].reshape(shape).copy())
+    return out
+
+
+def make_procedural_cloud(n: int, seed: int = 0xC10D5EED) -> np.ndarray:
+    """Synthetic benchmark cloud of SURVEY.md section 8(d): uint8 [n,n,n] texture."""
+    out = np.empty((n, n, n), np.uint8)
+    check(_lib.load().ct_make_procedural_cloud(n, seed & 0xFFFFFFFF, _p(out)))
+    return out
+
+
+def tile_owner(tx: int, ty: int, shard_count: int) -> int:
+    return int(_lib.load().ct_tile_owner(tx, ty, shard_count))
+
+
+def shard_mask(width: int, height: int, shard_index: int, shard_count: int) -> np.ndarray:
+    """bool [H, W]: pixels whose 8x8 tile belongs to `shard_index`."""
+    ty, tx = np.meshgrid(np.arange(height) // 8, np.arange(width) // 8, indexing="ij")
+    if shard_count <= 1:
+        return np.ones((height, width), bool)
+    return ((tx + 3 * ty) % shard_count) == shard_index
+
+
+@dataclass
+class SceneParams:
+    """Defaults = the reference's hard-coded configuration (SURVEY.md section 5 'config')."""
+    width: int = 512                       # Tasks.cpp:49
+    height: int = 256                      # Tasks.cpp:50
+    mode: int = 0                          # SunAndSkyAllScatter, Tasks.cpp:92
+    estimator: int = 0
+    cloud_size_m: float = 7000.0           # main.cpp:63
+    mean_free_path_m: float = 10.0         # SceneDescription.h:80
+    sample_step: float = 1.0 / 512.0       # installers.cpp:86
+    max_depth: int = 2000                  # cloudRadianceMaterials.cu:4
+    light_direction: tuple = LIGHT_DIRECTIONS["Side"]
+    light_color: tuple = (1.0, 1.0, 1.0)   # installers.cpp:99
+    light_intensity: float = 1e6           # installers.cpp:100
+    device: int = 0
+    shard_index: int = 0
+    shard_count: int = 1
+    flags: int = 0
+
+
+class CloudTracer:
+    """Owns one CtHandle.  `density` is the uint8 [Z,Y,X] texture incl. its zero border."""
+
+    def __init__(self, density: np.ndarray, params: SceneParams | None = None, **kw):
+        self.L = _lib.load()
+        self.params = params or SceneParams(**kw)
+        p = self.params
+        density = np.ascontiguousarray(density, np.uint8)
+        if density.ndim != 3:
+            raise ValueError("density must be uint8 [Z, Y, X]")
+        mie, chopped = load_mie_raw()
+        s = CtScene()
+        s.abi_version = _lib.CT_ABI_VERSION
+        nz, ny, nx = density.shape
+        s.dims[:] = (nx, ny, nz)
+        s.density_host = density.ctypes.data
+        s.cloud_size_m = p.cloud_size_m
+        s.mean_free_path_m = p.mean_free_path_m
+        s.sample_step = p.sample_step
+        s.mode = p.mode
+        s.estimator = p.estimator
+        s.max_depth = p.max_depth
+        s.light_direction[:] = p.light_direction
+        s.light_color[:] = p.light_color
+        s.light_intensity = p.light_intensity
+        s.width, s.height = p.width, p.height
+        s.mie_host = mie.ctypes.data
+        s.chopped_mie_host = chopped.ctypes.data
+        s.mie_count = 4096
+        s.device = p.device
+        s.shard_index, s.shard_count = p.shard_index, p.shard_count
+        s.flags = p.flags
+        self.dims = (nx, ny, nz)
+        self.width, self.height = p.width, p.height
+        h = C.c_void_p()
+        rc = self.L.ct_create(C.byref(s), C.byref(h))
+        check(rc, None)
+        self.h = h
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ct_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- ARenderer verbs ------------------------------------------------------------------------
+    def set_camera(self, eye, U, V, W):
+        a = [np.asarray(v, np.float32) for v in (eye, U, V, W)]
+        check(self.L.ct_set_camera(self.h, *[_p(v) for v in a]), self.h)
+
+    def render_subframe(self, subframe_id: int, out_dev_ptr: int | None = None):
+        check(self.L.ct_render_subframe(self.h, subframe_id, C.c_void_p(out_dev_ptr) if out_dev_ptr else None), self.h)
+
+    def accumulate(self, subframe_id: int, frame_dev_ptr: int | None = None):
+        check(self.L.ct_accumulate(self.h, subframe_id, C.c_void_p(frame_dev_ptr) if frame_dev_ptr else None), self.h)
+
+    def render_accumulate(self, first_subframe_id: int, count: int):
+        check(self.L.ct_render_accumulate(self.h, first_subframe_id, count), self.h)
+
+    def reset(self):
+        check(self.L.ct_reset(self.h), self.h)
+
+    def tonemap(self, exposure: float = 0.4):
+        """-> (uint8 [H,W,4] screen, average luminance)."""
+        screen = np.empty((self.height, self.width, 4), np.uint8)
+        avg = C.c_float(0)
+        check(self.L.ct_tonemap(self.h, exposure, _p(screen), C.byref(avg)), self.h)
+        return screen, float(avg.value)
+
+    def is_converged(self):
+        ok, bad = C.c_int32(0), C.c_uint64(0)
+        check(self.L.ct_is_converged(self.h, C.byref(ok), C.byref(bad)), self.h)
+        return bool(ok.value), int(bad.value)
+
+    # -- data ---------------------------------------------------------------------------------------
+    def download(self, which: int) -> np.ndarray:
+        n = C.c_size_t(0)
+        check(self.L.ct_buffer_bytes(self.h, which, C.byref(n)), self.h)
+        if which in (CT_BUF_MEAN, CT_BUF_M2, CT_BUF_FRAME):
+            out = np.empty((self.height, self.width, 4), np.float32)
+        elif which == CT_BUF_SCREEN:
+            out = np.empty((self.height, self.width, 4), np.uint8)
+        else:
+            nx, ny, nz = self.dims
+            out = np.empty((nz, ny, nx), np.uint8)
+        assert out.nbytes == n.value
+        check(self.L.ct_download(self.h, which, _p(out), out.nbytes), self.h)
+        return out
+
+    def mean(self):
+        return self.download(CT_BUF_MEAN)
+
+    def m2(self):
+        return self.download(CT_BUF_M2)
+
+    def frame(self):
+        return self.download(CT_BUF_FRAME)
+
+    def inscatter(self):
+        return self.download(CT_BUF_INSCATTER)
+
+    def copy_to_device(self, which: int, dst_dev_ptr: int, nbytes: int):
+        """D2D copy of a handle buffer into caller-owned device memory (e.g. a torch tensor)."""
+        check(self.L.ct_copy_to_device(self.h, which, C.c_void_p(dst_dev_ptr), nbytes), self.h)
+
+    def device_ptr(self, which: int) -> int:
+        p = C.c_void_p()
+        check(self.L.ct_device_ptr(self.h, which, C.byref(p)), self.h)
+        return int(p.value)
+
+    @property
+    def subframes(self) -> int:
+        n = C.c_uint32(0)
+        check(self.L.ct_subframes(self.h, C.byref(n)), self.h)
+        return int(n.value)
+
+    def set_subframes(self, n: int):
+        check(self.L.ct_set_subframes(self.h, n), self.h)
+
+    def counters(self) -> dict:
+        c = CtCounters()
+        check(self.L.ct_counters(self.h, C.byref(c)), self.h)
+        return c.as_dict()
+
+    def kernel_time(self):
+        """-> (estimator kernel ms, accumulate kernel ms, estimator launches) since create/reset."""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        check(self.L.ct_kernel_time(self.h, C.byref(a), C.byref(b), C.byref(n)), self.h)
+        return float(a.value), float(b.value), int(n.value)
+
+    def set_stream(self, hip_stream: int | None):
+        check(self.L.ct_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None), self.h)
+
+    def debug_cdf_inversion(self, first_u24: int, count: int) -> np.ndarray:
+        out = np.empty(count, np.uint32)
+        check(self.L.ct_debug_cdf_inversion(self.h, first_u24, count, _p(out)), self.h)
+        return out
+
+
+def algorithmic_bytes(counters: dict, pixels_times_spp: int) -> int:
+    """8 B per trilinear lookup (density or shadow volume) + 64 B per
+    pixel per subframe of accumulation."""
+    return 8 * (counters["density_lookups"] + counters["inscatter_lookups"]) + 64 * pixels_times_spp

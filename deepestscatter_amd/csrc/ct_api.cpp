@@ -1,0 +1,784 @@
+// ct_api.cpp -- the C ABI of include/cloudtrace.h on top of the gfx950 kernels.
+//
+// Host-side restatement of what the reference's scene items publish to OptiX before a
+// launch (Scene::init Scene.cpp:36-46, Sun::init Sun.cpp:13-18, VDBCloud::init
+// VDBCloud.cpp:15-137, Mie.cpp:8206-8297, Camera::init Camera.cpp:22-66), then thin launch
+// wrappers.  No exception leaves this file and nothing here falls back to a CPU path: if
+// HIP or the device is missing every entry point reports CT_E_NODEVICE / CT_E_HIP.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cloudtrace.h"
+#include "ct_internal.hpp"
+
+using namespace ct;
+
+struct CtHandle_ {
+    CtScene scene{};       // as given (host pointers are NOT retained)
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+
+    DevScene dev{};
+    bool camera_set = false;
+
+    // device memory
+    uint8_t *d_density = nullptr, *d_inscatter = nullptr;
+    uint2 *d_dcells = nullptr, *d_icells = nullptr;
+    float *d_mie = nullptr, *d_chopped = nullptr, *d_cdf = nullptr;
+    uint16_t *d_guide = nullptr;
+    float4 *d_frame = nullptr, *d_mean = nullptr, *d_m2 = nullptr;
+    uchar4 *d_screen = nullptr;
+    float4 *d_frames = nullptr; // batch scratch [S][H][W]
+    uint32_t frames_capacity = 0; // in subframes
+    uint32_t *d_tiles = nullptr;
+    uint32_t n_tiles = 0;
+    uint32_t *d_queue = nullptr;
+    unsigned long long *d_counters = nullptr; // kCounterCount + 1 (unconverged)
+    float *d_colsum = nullptr, *d_avg = nullptr;
+
+    size_t volume_bytes = 0;
+    LaunchShape shape{ 1024, 256 };
+    uint32_t subframes = 0;
+    double render_ms = 0, accum_ms = 0;
+    uint64_t launches = 0;
+    std::string error;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(CtHandle h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) {
+        h->error = buf;
+    } else {
+        g_create_error = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            return fail((h), e_ == hipErrorOutOfMemory ? CT_E_NOMEM : CT_E_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                      \
+        }                                                                                            \
+    } while (0)
+
+#define NEED(h)                                        \
+    do {                                               \
+        if (!(h)) {                                    \
+            return fail(nullptr, CT_E_INVAL, "null handle"); \
+        }                                              \
+        if (hipSetDevice((h)->device) != hipSuccess) { \
+            return fail((h), CT_E_HIP, "hipSetDevice(%d) failed", (h)->device); \
+        }                                              \
+    } while (0)
+
+static void v3_normalize_twice(const float in[3], float out[3])
+{
+    float v[3] = { in[0], in[1], in[2] };
+    for (int pass = 0; pass < 2; pass++) { // installers.cpp:74-78 then SceneDescription.h:16
+        const float inv = 1.0f / sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        v[0] *= inv;
+        v[1] *= inv;
+        v[2] *= inv;
+    }
+    out[0] = v[0];
+    out[1] = v[1];
+    out[2] = v[2];
+}
+
+// Mie.cpp:8206-8243: phase / mean(phase), float32 running sum in index order.
+static void mie_phase_texture(const float *raw, uint32_t n, std::vector<float> &out)
+{
+    out.resize(n);
+    float average = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        average += raw[i];
+    }
+    average /= (float)n;
+    for (uint32_t i = 0; i < n; i++) {
+        out[i] = raw[i] / average;
+    }
+}
+
+// Mie.cpp:8245-8282: running sum of phase / sum(phase).
+static void mie_integral_texture(const float *raw, uint32_t n, std::vector<float> &out)
+{
+    out.resize(n);
+    float sum = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        sum += raw[i];
+    }
+    float integral = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        integral += raw[i] / sum;
+        out[i] = integral;
+    }
+}
+
+// guide[b] = #{ i : cdf[i] < b / 4096 }, b = 0..4096 (+1 pad): brackets the texel search of
+// sample_cos_theta for every 24-bit random whose top 12 bits are b.
+static void build_guide(const std::vector<float> &cdf, std::vector<uint16_t> &guide)
+{
+    guide.assign(kGuideN + 2, 0);
+    uint32_t t = 0;
+    for (uint32_t b = 0; b <= (uint32_t)kGuideN; b++) {
+        const float edge = (float)b / (float)kGuideN;
+        while (t < cdf.size() && cdf[t] < edge) {
+            t++;
+        }
+        guide[b] = (uint16_t)t;
+    }
+    guide[kGuideN + 1] = guide[kGuideN];
+}
+
+static uint32_t morton2(uint32_t x, uint32_t y)
+{
+    auto spread = [](uint32_t v) {
+        v &= 0xffffu;
+        v = (v | (v << 8)) & 0x00ff00ffu;
+        v = (v | (v << 4)) & 0x0f0f0f0fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1);
+}
+
+template <typename T>
+static hipError_t dmalloc(T **p, size_t count)
+{
+    return hipMalloc((void **)p, count * sizeof(T));
+}
+
+static void release(CtHandle h)
+{
+    if (!h) {
+        return;
+    }
+    hipSetDevice(h->device);
+    if (h->stream) {
+        hipStreamSynchronize(h->stream);
+    }
+    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dcells, h->d_icells, h->d_mie, h->d_chopped, h->d_cdf,
+                     h->d_guide, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_tiles, h->d_queue,
+                     h->d_counters, h->d_colsum, h->d_avg };
+    for (void *p : ptrs) {
+        if (p) {
+            hipFree(p);
+        }
+    }
+    for (auto &e : h->ev) {
+        if (e) {
+            hipEventDestroy(e);
+        }
+    }
+    if (h->own_stream) {
+        hipStreamDestroy(h->own_stream);
+    }
+    delete h;
+}
+
+static int create_impl(const CtScene *s, CtHandle h)
+{
+    const uint32_t nx = s->dims[0], ny = s->dims[1], nz = s->dims[2];
+    const size_t texels = (size_t)nx * ny * nz;
+    h->scene = *s;
+    h->device = s->device;
+    h->volume_bytes = texels;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        return fail(h, CT_E_NODEVICE, "no HIP device visible (libcloudtrace has no CPU fallback)");
+    }
+    if (s->device < 0 || s->device >= ndev) {
+        return fail(h, CT_E_INVAL, "device %d out of range (0..%d)", s->device, ndev - 1);
+    }
+    HIPCHK(h, hipSetDevice(s->device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    for (auto &e : h->ev) {
+        HIPCHK(h, hipEventCreate(&e));
+    }
+    h->shape = persistent_shape(s->device);
+
+    // ---- uniforms: VDBCloud::setupVolumeVariables (VDBCloud.cpp:98-111), Sun::init (Sun.cpp:13-18)
+    DevScene &d = h->dev;
+    const float fx = (float)nx, fy = (float)ny, fz = (float)nz;
+    const float maxs = fmaxf(fmaxf(fx, fy), fz);
+    d.nx = (int32_t)nx;
+    d.ny = (int32_t)ny;
+    d.nz = (int32_t)nz;
+    d.bx = fx / maxs;
+    d.by = fy / maxs;
+    d.bz = fz / maxs;
+    d.hx = d.bx + 0.01f;
+    d.hy = d.by + 0.01f;
+    d.hz = d.bz + 0.01f;
+    d.sx = (maxs / fx) * fx; // textureScale * N
+    d.sy = (maxs / fy) * fy;
+    d.sz = (maxs / fz) * fz;
+    d.density_multiplier = s->cloud_size_m / s->mean_free_path_m;
+    d.sample_step = s->sample_step;
+    float l[3];
+    v3_normalize_twice(s->light_direction, l);
+    d.nlx = -l[0];
+    d.nly = -l[1];
+    d.nlz = -l[2];
+    d.lr = s->light_color[0] * s->light_intensity;
+    d.lg = s->light_color[1] * s->light_intensity;
+    d.lb = s->light_color[2] * s->light_intensity;
+    {
+        // cloud.cuh:148-151 evaluated once on the host, in float like the device code.
+        const float sunAngularRadiusDeg = 0.53f / 2;
+        const float sphereArea = 4 * kPi;
+        const float sunArea = 2 * kPi * (1 - cosf(sunAngularRadiusDeg * kPi / 180.0f));
+        d.sun_ratio = sunArea / sphereArea;
+    }
+    d.width = s->width;
+    d.height = s->height;
+    d.max_depth = s->max_depth;
+    d.mode = s->mode;
+    d.tiles_x = (s->width + kTile - 1) / kTile;
+    d.tiles_y = (s->height + kTile - 1) / kTile;
+
+    // apron: farthest texel a marching path can address (slack box + one step), see ct_device.hpp
+    const int apron = (int)ceilf((0.01f + s->sample_step) * fmaxf(fmaxf(d.sx, d.sy), d.sz) + 0.5f) + 1;
+    if (apron > 96) {
+        return fail(h, CT_E_INVAL, "sample_step %g too coarse for a %u^3 volume", (double)s->sample_step,
+                    (unsigned)maxs);
+    }
+    const int64_t cx = nx + 2 * apron + 1, cy = ny + 2 * apron + 1, cz = nz + 2 * apron + 1;
+    if (cx * cy >= (1ll << 31) / cz) {
+        return fail(h, CT_E_INVAL, "volume too large for 32-bit cell indices");
+    }
+    d.cell_sy = (int32_t)cx;
+    d.cell_sz = (int32_t)(cx * cy);
+    d.cell_origin = (int64_t)apron * (cx * cy + cx + 1);
+    const size_t n_cells = (size_t)(cx * cy * cz);
+
+    // ---- Mie textures (Mie.cpp:8206-8297) + guide table
+    std::vector<float> mie_tex, chopped_tex, cdf_tex;
+    std::vector<uint16_t> guide;
+    mie_phase_texture(s->mie_host, s->mie_count, mie_tex);
+    mie_phase_texture(s->chopped_mie_host, s->mie_count, chopped_tex);
+    mie_integral_texture(s->chopped_mie_host, s->mie_count, cdf_tex);
+    build_guide(cdf_tex, guide);
+    HIPCHK(h, dmalloc(&h->d_mie, kMieN));
+    HIPCHK(h, dmalloc(&h->d_chopped, kMieN));
+    HIPCHK(h, dmalloc(&h->d_cdf, kMieN));
+    HIPCHK(h, dmalloc(&h->d_guide, kGuideN + 2));
+    HIPCHK(h, hipMemcpyAsync(h->d_mie, mie_tex.data(), kMieN * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_chopped, chopped_tex.data(), kMieN * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_cdf, cdf_tex.data(), kMieN * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_guide, guide.data(), (kGuideN + 2) * sizeof(uint16_t), hipMemcpyHostToDevice,
+                             h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream)); // the vectors die at scope exit
+    d.mie = h->d_mie;
+    d.chopped = h->d_chopped;
+    d.cdf = h->d_cdf;
+    d.guide = h->d_guide;
+
+    // ---- density -> corner cells; shadow volume (VDBCloud::InitInScatter) -> corner cells
+    HIPCHK(h, dmalloc(&h->d_density, texels));
+    HIPCHK(h, dmalloc(&h->d_inscatter, texels));
+    HIPCHK(h, dmalloc(&h->d_dcells, n_cells));
+    HIPCHK(h, dmalloc(&h->d_icells, n_cells));
+    HIPCHK(h, hipMemcpyAsync(h->d_density, s->density_host, texels, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_build_cells(h->d_density, nx, ny, nz, apron, h->d_dcells, h->stream));
+    d.dcells = h->d_dcells;
+    d.icells = h->d_icells;
+    HIPCHK(h, launch_inscatter(d, h->d_inscatter, h->stream));
+    HIPCHK(h, launch_build_cells(h->d_inscatter, nx, ny, nz, apron, h->d_icells, h->stream));
+
+    // ---- Camera::init buffers (Camera.cpp:45-48) + reset (:77-86)
+    const size_t pixels = (size_t)s->width * s->height;
+    HIPCHK(h, dmalloc(&h->d_frame, pixels));
+    HIPCHK(h, dmalloc(&h->d_mean, pixels));
+    HIPCHK(h, dmalloc(&h->d_m2, pixels));
+    HIPCHK(h, dmalloc(&h->d_screen, pixels));
+    HIPCHK(h, dmalloc(&h->d_colsum, s->width));
+    HIPCHK(h, dmalloc(&h->d_avg, 1));
+    HIPCHK(h, dmalloc(&h->d_queue, 1));
+    HIPCHK(h, dmalloc(&h->d_counters, kCounterCount + 1));
+    HIPCHK(h, hipMemsetAsync(h->d_frame, 0, pixels * sizeof(float4), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_mean, 0, pixels * sizeof(float4), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_m2, 0, pixels * sizeof(float4), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_screen, 0, pixels * sizeof(uchar4), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1) * sizeof(unsigned long long), h->stream));
+
+    // ---- this shard's tiles, Morton order (neighbouring chunks of the queue stay close in the volume)
+    std::vector<std::pair<uint32_t, uint32_t>> order;
+    for (uint32_t ty = 0; ty < d.tiles_y; ty++) {
+        for (uint32_t tx = 0; tx < d.tiles_x; tx++) {
+            if (tile_owner(tx, ty, s->shard_count) == s->shard_index) {
+                order.emplace_back(morton2(tx, ty), ty * d.tiles_x + tx);
+            }
+        }
+    }
+    std::sort(order.begin(), order.end());
+    std::vector<uint32_t> tiles(order.size());
+    for (size_t i = 0; i < order.size(); i++) {
+        tiles[i] = order[i].second;
+    }
+    h->n_tiles = (uint32_t)tiles.size();
+    HIPCHK(h, dmalloc(&h->d_tiles, std::max<size_t>(tiles.size(), 1)));
+    if (!tiles.empty()) {
+        HIPCHK(h, hipMemcpyAsync(h->d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                 h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+
+    // ---- default pose: Camera.cpp:37-39 through sutil::calculateCameraVariables
+    const float eye[3] = { 2.5f, -0.4f, 0.f }, lookat[3] = { 0, 0, 0 }, up[3] = { 0, 1, 0 };
+    float U[3], V[3], W[3];
+    ct_calculate_camera_variables(eye, lookat, up, 30.0f, (float)s->width / (float)s->height, U, V, W);
+    return ct_set_camera(h, eye, U, V, W);
+}
+
+extern "C" int ct_create(const CtScene *s, CtHandle *out)
+{
+    if (!out) {
+        return fail(nullptr, CT_E_INVAL, "out is NULL");
+    }
+    *out = nullptr;
+    if (!s) {
+        return fail(nullptr, CT_E_INVAL, "scene is NULL");
+    }
+    if (s->abi_version != CT_ABI_VERSION) {
+        return fail(nullptr, CT_E_INVAL, "abi_version %u, library is %u", s->abi_version, CT_ABI_VERSION);
+    }
+    if (!s->density_host || s->dims[0] < 2 || s->dims[1] < 2 || s->dims[2] < 2 || s->dims[0] > 4096 ||
+        s->dims[1] > 4096 || s->dims[2] > 4096) {
+        return fail(nullptr, CT_E_INVAL, "density volume missing or dims out of range [2,4096]");
+    }
+    if (s->mode < 0 || s->mode > 2) {
+        return fail(nullptr, CT_E_INVAL, "Invalid Render Mode %d", s->mode); // CloudMaterial.cpp:62
+    }
+    if (s->estimator != CT_EST_MARCH) {
+        return fail(nullptr, CT_E_INVAL, "estimator %d not available in this build", s->estimator);
+    }
+    if (!s->mie_host || !s->chopped_mie_host || s->mie_count != (uint32_t)kMieN) {
+        return fail(nullptr, CT_E_INVAL, "Mie tables must be %d floats each", kMieN);
+    }
+    if (s->width == 0 || s->height == 0 || s->width > 16384 || s->height > 4096) {
+        return fail(nullptr, CT_E_INVAL, "frame %ux%u out of range (seed packing x*4096+y needs H <= 4096)", s->width,
+                    s->height);
+    }
+    if (!(s->sample_step > 0.f) || !(s->sample_step <= 0.25f) || !(s->cloud_size_m > 0.f) ||
+        !(s->mean_free_path_m > 0.f) || s->max_depth < 2) {
+        return fail(nullptr, CT_E_INVAL, "sample_step/cloud_size_m/mean_free_path_m/max_depth out of range");
+    }
+    if (!(s->cloud_size_m / s->mean_free_path_m * s->sample_step < 80.f)) {
+        return fail(nullptr, CT_E_INVAL, "optical depth per step %g too large (must be < 80)",
+                    (double)(s->cloud_size_m / s->mean_free_path_m * s->sample_step));
+    }
+    const float ll = s->light_direction[0] * s->light_direction[0] + s->light_direction[1] * s->light_direction[1] +
+                     s->light_direction[2] * s->light_direction[2];
+    if (!(ll > 0.f)) {
+        return fail(nullptr, CT_E_INVAL, "light_direction is zero");
+    }
+    if (s->shard_count == 0 || s->shard_index >= s->shard_count) {
+        return fail(nullptr, CT_E_INVAL, "shard %u of %u", s->shard_index, s->shard_count);
+    }
+    CtHandle h = new (std::nothrow) CtHandle_();
+    if (!h) {
+        return fail(nullptr, CT_E_NOMEM, "out of host memory");
+    }
+    const int rc = create_impl(s, h);
+    if (rc != CT_OK) {
+        g_create_error = h->error;
+        release(h);
+        return rc;
+    }
+    // host pointers are not retained
+    h->scene.density_host = nullptr;
+    h->scene.mie_host = nullptr;
+    h->scene.chopped_mie_host = nullptr;
+    *out = h;
+    return CT_OK;
+}
+
+extern "C" int ct_destroy(CtHandle h)
+{
+    release(h);
+    return CT_OK;
+}
+
+extern "C" const char *ct_last_error(CtHandle h)
+{
+    return h ? h->error.c_str() : g_create_error.c_str();
+}
+
+extern "C" int ct_set_stream(CtHandle h, void *hip_stream)
+{
+    NEED(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return CT_OK;
+}
+
+extern "C" int ct_set_camera(CtHandle h, const float eye[3], const float U[3], const float V[3], const float W[3])
+{
+    NEED(h);
+    if (!eye || !U || !V || !W) {
+        return fail(h, CT_E_INVAL, "camera vectors must not be NULL");
+    }
+    DevScene &d = h->dev;
+    d.ex = eye[0]; d.ey = eye[1]; d.ez = eye[2];
+    d.ux = U[0]; d.uy = U[1]; d.uz = U[2];
+    d.vx = V[0]; d.vy = V[1]; d.vz = V[2];
+    d.wx = W[0]; d.wy = W[1]; d.wz = W[2];
+    h->camera_set = true;
+    return CT_OK;
+}
+
+static int ensure_frames(CtHandle h, uint32_t S)
+{
+    if (S <= h->frames_capacity) {
+        return CT_OK;
+    }
+    if (h->d_frames) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(h->d_frames));
+        h->d_frames = nullptr;
+        h->frames_capacity = 0;
+    }
+    HIPCHK(h, dmalloc(&h->d_frames, (size_t)S * h->scene.width * h->scene.height));
+    h->frames_capacity = S;
+    return CT_OK;
+}
+
+// One launch of the estimator over S subframes into `frames` (+ optional accumulate).
+static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, bool accumulate)
+{
+    BatchArgs ba{};
+    ba.frames = frames;
+    ba.tiles = h->d_tiles;
+    ba.n_tiles = h->n_tiles;
+    ba.first_subframe = first;
+    ba.S = S;
+    ba.total = h->n_tiles * S * 64u;
+    ba.queue = h->d_queue;
+    ba.counters = h->d_counters;
+    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    if (h->n_tiles != 0) {
+        if (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) {
+            for (uint32_t s = 0; s < S; s++) {
+                BatchArgs one = ba;
+                one.frames = frames + (size_t)s * h->scene.width * h->scene.height;
+                one.first_subframe = first + s;
+                one.S = 1;
+                HIPCHK(h, launch_render_simple(h->dev, one, h->scene.shard_index, h->scene.shard_count, h->stream));
+            }
+        } else {
+            HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+        }
+    }
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    if (accumulate) {
+        HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, first, S, h->scene.width, h->scene.height,
+                                          h->scene.shard_index, h->scene.shard_count, h->stream));
+    }
+    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev[2]));
+    float ms01 = 0, ms12 = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms01, h->ev[0], h->ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&ms12, h->ev[1], h->ev[2]));
+    h->render_ms += ms01;
+    h->accum_ms += ms12;
+    h->launches += 1;
+    return CT_OK;
+}
+
+extern "C" int ct_render_subframe(CtHandle h, uint32_t subframe_id, float *frame_rgba_dev)
+{
+    NEED(h);
+    if (!h->camera_set) {
+        return fail(h, CT_E_STATE, "ct_set_camera has not been called");
+    }
+    const size_t bytes = (size_t)h->scene.width * h->scene.height * sizeof(float4);
+    // pixels of other shards (and nothing else) stay (0,0,0,0)
+    HIPCHK(h, hipMemsetAsync(h->d_frame, 0, bytes, h->stream));
+    const int rc = run_batch(h, h->d_frame, subframe_id, 1, false);
+    if (rc != CT_OK) {
+        return rc;
+    }
+    if (frame_rgba_dev) {
+        HIPCHK(h, hipMemcpyAsync(frame_rgba_dev, h->d_frame, bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *frame_rgba_dev)
+{
+    NEED(h);
+    if (subframe_id == 0) {
+        return fail(h, CT_E_INVAL, "subframe ids are 1-based (Camera.cpp:191)");
+    }
+    const float4 *src = frame_rgba_dev ? (const float4 *)frame_rgba_dev : h->d_frame;
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(h, launch_accumulate_batch(src, h->d_mean, h->d_m2, subframe_id, 1, h->scene.width, h->scene.height,
+                                      h->scene.shard_index, h->scene.shard_count, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev[2]));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
+    h->accum_ms += ms;
+    h->subframes = subframe_id;
+    return CT_OK;
+}
+
+extern "C" int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint32_t count)
+{
+    NEED(h);
+    if (!h->camera_set) {
+        return fail(h, CT_E_STATE, "ct_set_camera has not been called");
+    }
+    if (first_subframe_id != h->subframes + 1) {
+        return fail(h, CT_E_STATE, "first_subframe_id %u but %u subframes are accumulated", first_subframe_id,
+                    h->subframes);
+    }
+    if (count == 0) {
+        return CT_OK;
+    }
+    // split so that the scratch stays <= 4 GiB and sample / pixel indices fit 32 bits
+    const uint64_t plane = (uint64_t)h->scene.width * h->scene.height;
+    uint64_t cap = std::min<uint64_t>((4ull << 30) / (plane * sizeof(float4)), 0xffffffffull / std::max<uint64_t>(plane, 1));
+    cap = std::min<uint64_t>(cap, 0xffffffffull / (std::max<uint64_t>(h->n_tiles, 1) * 64ull));
+    cap = std::max<uint64_t>(std::min<uint64_t>(cap, 1024), 1);
+    uint32_t done = 0;
+    while (done < count) {
+        const uint32_t S = (uint32_t)std::min<uint64_t>(cap, count - done);
+        int rc = ensure_frames(h, S);
+        if (rc != CT_OK) {
+            return rc;
+        }
+        rc = run_batch(h, h->d_frames, first_subframe_id + done, S, true);
+        if (rc != CT_OK) {
+            return rc;
+        }
+        done += S;
+        h->subframes += S;
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_reset(CtHandle h)
+{
+    NEED(h);
+    const size_t pixels = (size_t)h->scene.width * h->scene.height;
+    HIPCHK(h, hipMemsetAsync(h->d_frame, 0, pixels * sizeof(float4), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_mean, 0, pixels * sizeof(float4), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_m2, 0, pixels * sizeof(float4), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1) * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->subframes = 0;
+    h->render_ms = h->accum_ms = 0;
+    h->launches = 0;
+    return CT_OK;
+}
+
+extern "C" int ct_tonemap(CtHandle h, float exposure, uint8_t *rgba_host, float *avg_luminance_out)
+{
+    NEED(h);
+    HIPCHK(h, launch_reinhard(h->d_mean, h->scene.width, h->scene.height, exposure, h->d_colsum, h->d_avg,
+                              h->d_screen, h->stream));
+    if (rgba_host) {
+        HIPCHK(h, hipMemcpyAsync(rgba_host, h->d_screen, (size_t)h->scene.width * h->scene.height * sizeof(uchar4),
+                                 hipMemcpyDeviceToHost, h->stream));
+    }
+    if (avg_luminance_out) {
+        HIPCHK(h, hipMemcpyAsync(avg_luminance_out, h->d_avg, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CT_OK;
+}
+
+extern "C" int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unconverged_pixels_out)
+{
+    NEED(h);
+    if (!converged_out) {
+        return fail(h, CT_E_INVAL, "converged_out is NULL");
+    }
+    const uint64_t pixels = (uint64_t)h->scene.width * h->scene.height;
+    if (h->subframes < 100) { // Camera.cpp:234-237
+        *converged_out = 0;
+        if (unconverged_pixels_out) {
+            *unconverged_pixels_out = pixels;
+        }
+        return CT_OK;
+    }
+    unsigned long long *d_cnt = h->d_counters + kCounterCount;
+    HIPCHK(h, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
+    HIPCHK(h, launch_converged(h->d_mean, h->d_m2, h->subframes, pixels, d_cnt, h->stream));
+    unsigned long long bad = 0;
+    HIPCHK(h, hipMemcpyAsync(&bad, d_cnt, sizeof bad, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *converged_out = bad < 500 ? 1 : 0; // Camera.cpp:267
+    if (unconverged_pixels_out) {
+        *unconverged_pixels_out = bad;
+    }
+    return CT_OK;
+}
+
+static int buffer_info(CtHandle h, int32_t which, void **ptr, size_t *bytes)
+{
+    const size_t pixels = (size_t)h->scene.width * h->scene.height;
+    switch (which) {
+    case CT_BUF_MEAN: *ptr = h->d_mean; *bytes = pixels * sizeof(float4); return CT_OK;
+    case CT_BUF_M2: *ptr = h->d_m2; *bytes = pixels * sizeof(float4); return CT_OK;
+    case CT_BUF_FRAME: *ptr = h->d_frame; *bytes = pixels * sizeof(float4); return CT_OK;
+    case CT_BUF_SCREEN: *ptr = h->d_screen; *bytes = pixels * sizeof(uchar4); return CT_OK;
+    case CT_BUF_INSCATTER: *ptr = h->d_inscatter; *bytes = h->volume_bytes; return CT_OK;
+    case CT_BUF_DENSITY: *ptr = h->d_density; *bytes = h->volume_bytes; return CT_OK;
+    default: return fail(h, CT_E_INVAL, "unknown buffer %d", which);
+    }
+}
+
+extern "C" int ct_buffer_bytes(CtHandle h, int32_t which, size_t *bytes_out)
+{
+    NEED(h);
+    void *p;
+    size_t b = 0;
+    const int rc = buffer_info(h, which, &p, &b);
+    if (rc == CT_OK && bytes_out) {
+        *bytes_out = b;
+    }
+    return rc;
+}
+
+extern "C" int ct_download(CtHandle h, int32_t which, void *dst_host, size_t dst_bytes)
+{
+    NEED(h);
+    void *p;
+    size_t b = 0;
+    const int rc = buffer_info(h, which, &p, &b);
+    if (rc != CT_OK) {
+        return rc;
+    }
+    if (!dst_host || dst_bytes != b) {
+        return fail(h, CT_E_INVAL, "ct_download: need %zu bytes, got %zu", b, dst_bytes);
+    }
+    HIPCHK(h, hipMemcpyAsync(dst_host, p, b, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CT_OK;
+}
+
+extern "C" int ct_copy_to_device(CtHandle h, int32_t which, void *dst_dev, size_t dst_bytes)
+{
+    NEED(h);
+    void *p;
+    size_t b = 0;
+    const int rc = buffer_info(h, which, &p, &b);
+    if (rc != CT_OK) {
+        return rc;
+    }
+    if (!dst_dev || dst_bytes != b) {
+        return fail(h, CT_E_INVAL, "ct_copy_to_device: need %zu bytes, got %zu", b, dst_bytes);
+    }
+    HIPCHK(h, hipMemcpyAsync(dst_dev, p, b, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CT_OK;
+}
+
+extern "C" int ct_device_ptr(CtHandle h, int32_t which, void **ptr_out)
+{
+    NEED(h);
+    size_t b = 0;
+    if (!ptr_out) {
+        return fail(h, CT_E_INVAL, "ptr_out is NULL");
+    }
+    return buffer_info(h, which, ptr_out, &b);
+}
+
+extern "C" int ct_subframes(CtHandle h, uint32_t *count_out)
+{
+    NEED(h);
+    if (count_out) {
+        *count_out = h->subframes;
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_set_subframes(CtHandle h, uint32_t count)
+{
+    NEED(h);
+    h->subframes = count;
+    return CT_OK;
+}
+
+extern "C" int ct_counters(CtHandle h, CtCounters *out)
+{
+    NEED(h);
+    if (!out) {
+        return fail(h, CT_E_INVAL, "out is NULL");
+    }
+    unsigned long long c[kCounterCount];
+    HIPCHK(h, hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out->paths = c[0];
+    out->box_hits = c[1];
+    out->density_lookups = c[2];
+    out->inscatter_lookups = c[3];
+    out->scatter_events = c[4];
+    out->depth_capped = c[5];
+    return CT_OK;
+}
+
+extern "C" int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_ms_out, uint64_t *launches_out)
+{
+    NEED(h);
+    if (render_ms_out) {
+        *render_ms_out = h->render_ms;
+    }
+    if (accumulate_ms_out) {
+        *accumulate_ms_out = h->accum_ms;
+    }
+    if (launches_out) {
+        *launches_out = h->launches;
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_debug_cdf_inversion(CtHandle h, uint32_t first_u24, uint32_t count, uint32_t *k_host_out)
+{
+    NEED(h);
+    if (!k_host_out || count == 0 || (uint64_t)first_u24 + count > (1ull << 24)) {
+        return fail(h, CT_E_INVAL, "range must lie inside [0, 2^24)");
+    }
+    uint32_t *d_k = nullptr;
+    HIPCHK(h, dmalloc(&d_k, count));
+    hipError_t e = launch_cdf_selftest(h->d_cdf, h->d_guide, first_u24, count, d_k, h->stream);
+    if (e == hipSuccess) {
+        e = hipMemcpyAsync(k_host_out, d_k, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess) {
+        e = hipStreamSynchronize(h->stream);
+    }
+    hipFree(d_k);
+    HIPCHK(h, e);
+    return CT_OK;
+}
+
+extern "C" uint32_t ct_tile_owner(uint32_t tile_x, uint32_t tile_y, uint32_t shard_count)
+{
+    return tile_owner(tile_x, tile_y, shard_count);
+}

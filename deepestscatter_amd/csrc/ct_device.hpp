@@ -1,0 +1,264 @@
+// ct_device.hpp -- device-side building blocks of the gfx950 cloud path tracer.
+//
+// Everything here is written for CDNA4 (wave64, no texture filtering hardware): the
+// reference's texture fetches (cloud.cuh:58-68) become ONE 8-byte global load of a
+// pre-gathered 2x2x2 "corner cell" followed by an explicit float trilinear filter; the
+// Mie tables live in LDS; the CDF inversion (cloud.cuh:160-180) is a guide-table search
+// that returns exactly what the reference's 16-step bisection returns.
+//
+// Arithmetic contract: include/ct_fmath.h + -ffp-contract=off.  Operation order follows
+// the reference line by line where the reference's own code fixes it; see DESIGN.md.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ct_fmath.h"
+
+namespace ct {
+
+#define CT_DEV __device__ __forceinline__
+
+struct f3 {
+    float x, y, z;
+};
+
+CT_DEV f3 mk3(float x, float y, float z) { return f3{ x, y, z }; }
+CT_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+CT_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+CT_DEV f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+CT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+CT_DEV f3 cross3(f3 a, f3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// optix::normalize = v * (1.0f / sqrtf(dot(v,v)))  (OptiX SDK optixu_math_namespace.h)
+CT_DEV f3 normalize3(f3 a)
+{
+    const float inv = 1.0f / sqrtf(dot3(a, a));
+    return scale3(a, inv);
+}
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr int kMieN = 4096;           // entries per Mie table (Mie.cpp:8-8203)
+constexpr int kGuideN = 4096;         // buckets of the CDF guide table
+constexpr float kFracMax = 0x1.fffffep-1f;
+
+// All uniforms of the path: the OptiX variable scopes of SURVEY section 8b, flattened.
+struct DevScene {
+    // corner-cell volumes: cell(ix,iy,iz) = the 8 texels {ix,ix+1}x{iy,iy+1}x{iz,iz+1},
+    // clamp-to-edge applied, byte order bit0=x bit1=y bit2=z; an apron of `apron` cells on
+    // every side makes the clamp implicit for every position the tracer can reach.
+    const uint2 *dcells;   // density
+    const uint2 *icells;   // inScatter (shadow volume)
+    int32_t cell_sy;       // cells per row
+    int32_t cell_sz;       // cells per slice
+    int64_t cell_origin;   // index of cell (0,0,0)
+    int32_t nx, ny, nz;    // texels
+    float sx, sy, sz;      // box coordinate -> texel coordinate (textureScale * N)
+    float bx, by, bz;      // bboxSize          (VDBCloud.cpp:104)
+    float hx, hy, hz;      // bboxSize + 0.01f  (cloud.cuh:43)
+    float density_multiplier;  // VDBCloud.cpp:109
+    float sample_step;         // CloudMaterial.cpp:14
+    float nlx, nly, nlz;   // -lightDirection   (cloud.cuh:153)
+    float lr, lg, lb;      // lightColor * lightIntensity
+    float sun_ratio;       // sunToSphereAreaRatio, cloud.cuh:148-151
+    const float *mie;      // un-chopped phase texture (global; used once per path)
+    const float *chopped;  // chopped phase texture   (copied to LDS)
+    const float *cdf;      // chopped CDF texture     (copied to LDS)
+    const uint16_t *guide; // kGuideN+2 entries       (copied to LDS)
+    float ex, ey, ez, ux, uy, uz, vx, vy, vz, wx, wy, wz; // eye, U, V, W
+    uint32_t width, height;
+    uint32_t max_depth;
+    int32_t mode;
+    uint32_t tiles_x, tiles_y;
+};
+
+// ---- RNG: random.cuh:34-70 (tea<4> with v1 = subframeId) -------------------
+CT_DEV uint32_t tea4(uint32_t v0, uint32_t v1)
+{
+    uint32_t s0 = 0;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+
+CT_DEV uint32_t lcg24(uint32_t &prev)
+{
+    prev = 1664525u * prev + 1013904223u;
+    return prev & 0x00FFFFFFu;
+}
+
+CT_DEV float u24_to_float(uint32_t u) { return (float)u / (float)0x01000000; }
+
+// ---- isInBox, cloud.cuh:40-44 ------------------------------------------------------------
+CT_DEV bool in_box(const DevScene &sc, f3 p)
+{
+    return p.x >= -0.01f && p.y >= -0.01f && p.z >= -0.01f && p.x <= sc.hx && p.y <= sc.hy && p.z <= sc.hz;
+}
+
+// ---- 3-D texture unit ---------------------------------------------------------------------
+// floor / frac of a texel coordinate; v_fract_f32 returns min(x - floor(x), 0x1.fffffep-1)
+// which is exactly the oracle's fracf().
+CT_DEV float fract_(float x) { return __builtin_amdgcn_fractf(x); }
+
+// Trilinear filter of one corner cell: x, then y, then z; lerp(a,b,t)=fma(t,b-a,a); /255 last.
+CT_DEV float filter_cell(uint2 c, float wx, float wy, float wz)
+{
+    const float t000 = (float)(c.x & 0xffu), t100 = (float)((c.x >> 8) & 0xffu);
+    const float t010 = (float)((c.x >> 16) & 0xffu), t110 = (float)(c.x >> 24);
+    const float t001 = (float)(c.y & 0xffu), t101 = (float)((c.y >> 8) & 0xffu);
+    const float t011 = (float)((c.y >> 16) & 0xffu), t111 = (float)(c.y >> 24);
+    const float c00 = fmaf(wx, t100 - t000, t000), c10 = fmaf(wx, t110 - t010, t010);
+    const float c01 = fmaf(wx, t101 - t001, t001), c11 = fmaf(wx, t111 - t011, t011);
+    const float c0 = fmaf(wy, c10 - c00, c00), c1 = fmaf(wy, c11 - c01, c01);
+    return fmaf(wz, c1 - c0, c0) * (1.0f / 255.0f);
+}
+
+// tex3D for positions the tracer can reach (inside the slack box +- one step): no clamp, the
+// apron supplies clamp-to-edge.
+CT_DEV float tex3_apron(const DevScene &sc, const uint2 *cells, f3 p)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    const float flx = floorf(x), fly = floorf(y), flz = floorf(z);
+    const int32_t ix = (int32_t)flx, iy = (int32_t)fly, iz = (int32_t)flz;
+    const int64_t idx = sc.cell_origin + (int64_t)(iz * sc.cell_sz + iy * sc.cell_sy + ix);
+    const uint2 c = cells[idx];
+    return filter_cell(c, fract_(x), fract_(y), fract_(z));
+}
+
+// tex3D with explicit clamp-to-edge, for the shadow-volume precompute which marches up to
+// one box length away from the box (inScatter.cu:55-59 has no box test).
+CT_DEV float tex3_clamped(const DevScene &sc, const uint2 *cells, f3 p)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    const float flx = floorf(x), fly = floorf(y), flz = floorf(z);
+    // clamp in float first (far-away positions would overflow the int conversion)
+    const int32_t ix = (int32_t)fminf(fmaxf(flx, -1.0f), (float)(sc.nx - 1));
+    const int32_t iy = (int32_t)fminf(fmaxf(fly, -1.0f), (float)(sc.ny - 1));
+    const int32_t iz = (int32_t)fminf(fmaxf(flz, -1.0f), (float)(sc.nz - 1));
+    const int64_t idx = sc.cell_origin + (int64_t)(iz * sc.cell_sz + iy * sc.cell_sy + ix);
+    const uint2 c = cells[idx];
+    return filter_cell(c, fract_(x), fract_(y), fract_(z));
+}
+
+// ---- 1-D texture unit on a float table (Mie.cpp:8229-8240): linear, clamp, normalised -----
+template <typename Ptr>
+CT_DEV float tex1(Ptr t, float u)
+{
+    const float x = fmaf(u, (float)kMieN, -0.5f);
+    const float fl = floorf(x);
+    const int32_t i = (int32_t)fl;
+    const int32_t i0 = min(max(i, 0), kMieN - 1);
+    const int32_t i1 = min(max(i + 1, 0), kMieN - 1);
+    const float a = t[i0], b = t[i1];
+    return fmaf(fract_(x), b - a, a);
+}
+
+// ---- CDF inversion ------------------------------------------------------------------------
+// The reference bisects 16 times on tex1D(choppedMieIntegral, m) (cloud.cuh:162-180) and
+// returns cosTheta = l + r - 1 with l = k/65536, r = (k+1)/65536, where
+//     k = #{ j in 1..65535 : tex1D(cdf, j/65536) < val }
+// because the filtered CDF is monotone.  tex1D at j/65536 sits in texel i = (j-8)>>4 with
+// weight ((j-8)&15)/16, so with t = #{ i : cdf[i] < val } (found from a 4096-bucket guide
+// table + a short binary search) only the 15 interior points of texel t-1 remain:
+//     k = min(16(t-1) + 8 + s, 65535),   s = #{ s' in 1..15 : fma(s'/16, cdf[t]-cdf[t-1], cdf[t-1]) < val }.
+// tests/test_cdf_inversion.py checks all 2^24 values of val against the literal bisection.
+template <typename CdfPtr, typename GuidePtr>
+CT_DEV float sample_cos_theta(CdfPtr cdf, GuidePtr guide, uint32_t u24)
+{
+    const float val = u24_to_float(u24);
+    const uint32_t bucket = u24 >> 12;
+    uint32_t lo = guide[bucket], hi = guide[bucket + 1];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] < val) {
+            lo = mid + 1;
+        } else {
+            hi = mid;
+        }
+    }
+    const uint32_t t = lo; // smallest t with cdf[t] >= val, or 4096
+    uint32_t k = 0;
+    if (t != 0) {
+        const float a = cdf[t - 1];
+        const float b = cdf[min(t, (uint32_t)kMieN - 1)];
+        const float d = b - a;
+        uint32_t s = 0; // largest s' in 0..15 with f(s') < val (f(0) = a < val)
+#pragma unroll
+        for (uint32_t bit = 8; bit != 0; bit >>= 1) {
+            const uint32_t cand = s | bit;
+            const float f = fmaf((float)cand * 0.0625f, d, a);
+            s = (f < val) ? cand : s;
+        }
+        k = min(16u * (t - 1) + 8u + s, 65535u);
+    }
+    return (float)(2u * k + 1u) * (1.0f / 65536.0f) - 1.0f;
+}
+
+// ---- getNewDirection, cloud.cuh:160-188 + uniformOnSphereCircle random.cuh:122-131 + Onb ----
+template <typename CdfPtr, typename GuidePtr>
+CT_DEV f3 new_direction(CdfPtr cdf, GuidePtr guide, uint32_t &seed, f3 prev)
+{
+    const float cos_theta = sample_cos_theta(cdf, guide, lcg24(seed));
+    const float phi = u24_to_float(lcg24(seed)) * kPi * 2;
+    const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+    float sn, cs;
+    ct_sincosf(phi, &sn, &cs);
+    const float px = sin_theta * cs, py = sin_theta * sn, pz = cos_theta;
+    // optix::Onb(prev)
+    f3 b;
+    if (fabsf(prev.x) > fabsf(prev.z)) {
+        b = mk3(-prev.y, prev.x, 0.0f);
+    } else {
+        b = mk3(0.0f, -prev.z, prev.y);
+    }
+    b = normalize3(b);
+    const f3 tg = cross3(b, prev);
+    // inverse_transform: p.x*tangent + p.y*binormal + p.z*normal
+    const f3 r = add3(add3(scale3(tg, px), scale3(b, py)), scale3(prev, pz));
+    return normalize3(r);
+}
+
+// ---- intersect, cloudBBox.cu:7-37 -----------------------------------------------------------
+CT_DEV bool intersect_box(const DevScene &sc, f3 o, f3 d, float &t_hit)
+{
+    const float nxh = -sc.bx / 2, nyh = -sc.by / 2, nzh = -sc.bz / 2;
+    const float pxh = sc.bx / 2, pyh = sc.by / 2, pzh = sc.bz / 2;
+    const float t0x = (nxh - o.x) / d.x, t0y = (nyh - o.y) / d.y, t0z = (nzh - o.z) / d.z;
+    const float t1x = (pxh - o.x) / d.x, t1y = (pyh - o.y) / d.y, t1z = (pzh - o.z) / d.z;
+    const float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    const float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    if (tmin <= tmax) {
+        if (tmin > 0.0f && tmin < 1e27f) {
+            t_hit = tmin;
+            return true;
+        }
+        t_hit = 0.000001f; // minimalRayDistance, CloudMaterial.cpp:23
+        return true;
+    }
+    return false;
+}
+
+// ---- exp for the march: arguments are -sigma*step in (-87, 0], so ct_expf's range checks
+// can never fire; same instruction sequence otherwise (bit-identical for in-range x). ---------
+CT_DEV float expf_inrange(float x)
+{
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float y = fmaf(p, r * r, r) + 1.0f;
+    return y * ct_bits_to_float((uint32_t)((int32_t)n + 127) << 23);
+}
+
+} // namespace ct

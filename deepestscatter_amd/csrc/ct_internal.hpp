@@ -1,0 +1,54 @@
+// ct_internal.hpp -- launcher declarations shared by ct_kernels.hip and ct_api.cpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ct_device.hpp"
+
+namespace ct {
+
+constexpr int kTile = 8;            // pixel tile edge: 8x8 = one wave of primary rays
+constexpr int kCounterCount = 6;    // paths, box_hits, density, inscatter, scatter, capped
+
+// One progressive batch: subframes first .. first+S-1 of the handle's own tiles.
+struct BatchArgs {
+    float4 *frames;            // [S][H][W] per-sample results (frameResultBuffer x S)
+    const uint32_t *tiles;     // tile ids owned by this shard, in traversal order
+    uint32_t n_tiles;
+    uint32_t first_subframe;   // 1-based subframeId of slice 0
+    uint32_t S;
+    uint32_t total;            // n_tiles * S * 64 samples in the queue
+    uint32_t *queue;           // global work counter, zero before launch
+    unsigned long long *counters; // kCounterCount
+};
+
+struct LaunchShape {
+    int blocks;
+    int threads;
+};
+
+// Tile -> shard map (also exported as ct_tile_owner).
+__host__ __device__ inline uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_t shard_count)
+{
+    return shard_count <= 1 ? 0u : (tx + 3u * ty) % shard_count;
+}
+
+hipError_t launch_build_cells(const uint8_t *texels, int nx, int ny, int nz, int apron, uint2 *cells,
+                              hipStream_t stream);
+hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream);
+hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
+hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_t shard_index,
+                                uint32_t shard_count, hipStream_t stream);
+hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
+                                   uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
+                                   uint32_t shard_count, hipStream_t stream);
+hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure,
+                           float *column_sums, float *avg, uchar4 *screen, hipStream_t stream);
+hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,
+                            unsigned long long *unconverged, hipStream_t stream);
+hipError_t launch_cdf_selftest(const float *cdf, const uint16_t *guide, uint32_t first_u24, uint32_t count,
+                               uint32_t *k_out, hipStream_t stream);
+LaunchShape persistent_shape(int device);
+
+} // namespace ct

@@ -1,0 +1,629 @@
+// ct_kernels.hip -- gfx950 kernels of the cloud path tracer.
+//
+//   render_persistent_kernel   the estimator (cloudRadianceMaterials.cu:9-148 + cloud.cuh:77-188 +
+//                              pathTracingCamera.cu:12-21 + cloudBBox.cu:7-37) as a persistent,
+//                              wave-scheduled state machine with path regeneration
+//   render_simple_kernel       the same estimator, one thread per pixel, nested loops (A/B and
+//                              cross-check only)
+//   accumulate_batch_kernel    updateFrameResult (progressive.cu:17-27) over S subframes in order
+//   inscatter_kernel           inScatter.cu:40-66
+//   build_cells_kernel         uint8 volume -> 8-byte corner cells (replaces the texture unit)
+//   reinhard_*                 reinhard.cu:26-84
+//   converged_kernel           Camera::isConverged (Camera.cpp:232-268)
+//
+// Compile with -ffp-contract=off: results must be bit-identical to oracle/ct_oracle.c.
+#include "ct_internal.hpp"
+
+namespace ct {
+
+// =============================================================================================
+// corner cells
+// =============================================================================================
+__global__ void build_cells_kernel(const uint8_t *__restrict__ t, int nx, int ny, int nz, int apron,
+                                   uint2 *__restrict__ cells, int cx, int cy, int cz)
+{
+    const int64_t total = (int64_t)cx * cy * cz;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % cx) - apron;
+        const int y = (int)((i / cx) % cy) - apron;
+        const int z = (int)(i / ((int64_t)cx * cy)) - apron;
+        const int x0 = min(max(x, 0), nx - 1), x1 = min(max(x + 1, 0), nx - 1);
+        const int y0 = min(max(y, 0), ny - 1), y1 = min(max(y + 1, 0), ny - 1);
+        const int z0 = min(max(z, 0), nz - 1), z1 = min(max(z + 1, 0), nz - 1);
+        const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+        uint2 c;
+        c.x = (uint32_t)t[z0 * sz + y0 * sy + x0] | ((uint32_t)t[z0 * sz + y0 * sy + x1] << 8) |
+              ((uint32_t)t[z0 * sz + y1 * sy + x0] << 16) | ((uint32_t)t[z0 * sz + y1 * sy + x1] << 24);
+        c.y = (uint32_t)t[z1 * sz + y0 * sy + x0] | ((uint32_t)t[z1 * sz + y0 * sy + x1] << 8) |
+              ((uint32_t)t[z1 * sz + y1 * sy + x0] << 16) | ((uint32_t)t[z1 * sz + y1 * sy + x1] << 24);
+        cells[i] = c;
+    }
+}
+
+hipError_t launch_build_cells(const uint8_t *texels, int nx, int ny, int nz, int apron, uint2 *cells,
+                              hipStream_t stream)
+{
+    const int cx = nx + 2 * apron + 1, cy = ny + 2 * apron + 1, cz = nz + 2 * apron + 1;
+    const int64_t total = (int64_t)cx * cy * cz;
+    const int threads = 256;
+    const int blocks = (int)((total + threads - 1) / threads < 16384 ? (total + threads - 1) / threads : 16384);
+    hipLaunchKernelGGL(build_cells_kernel, dim3(blocks), dim3(threads), 0, stream, texels, nx, ny, nz, apron, cells,
+                       cx, cy, cz);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// shadow volume  (inScatter.cu:40-66): sample, THEN step; <= 1/sampleStep steps; early out
+// when T*255 < 1; uchar(T*255) truncating.  One thread per texel.
+// =============================================================================================
+__global__ __launch_bounds__(256) void inscatter_kernel(DevScene sc, uint8_t *__restrict__ out)
+{
+    const int64_t total = (int64_t)sc.nx * sc.ny * sc.nz;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) {
+        return;
+    }
+    const int x = (int)(i % sc.nx), y = (int)((i / sc.nx) % sc.ny), z = (int)(i / ((int64_t)sc.nx * sc.ny));
+    const float max_size = (float)max(max(sc.nx, sc.ny), sc.nz);
+    // textureScale = sx / nx etc. was folded on the host; min(textureScale) is passed in sun_ratio's
+    // neighbour: recompute it exactly as the host did (float division, same operands).
+    const float tsx = max_size / (float)sc.nx, tsy = max_size / (float)sc.ny, tsz = max_size / (float)sc.nz;
+    const float min_scale = fminf(fminf(tsx, tsy), tsz);
+    const float inv_min_scale = 1.0f / min_scale;
+    f3 p = mk3((float)x / max_size, (float)y / max_size, (float)z / max_size);
+    p = scale3(p, inv_min_scale);
+    // stepToLight = (-normalize(lightDirection)) * sampleStep; (nlx,nly,nlz) = -lightDirection and
+    // normalize(-v) = -normalize(v) exactly (sign symmetry of every operation involved).
+    const f3 step_to_light = scale3(normalize3(mk3(sc.nlx, sc.nly, sc.nlz)), sc.sample_step);
+    const int step_count = (int)(1 / sc.sample_step);
+    float transmittance = 1;
+    for (int s = 0; s < step_count; s++) {
+        const float density = tex3_clamped(sc, sc.dcells, p) * sc.density_multiplier;
+        const float extinction = density * sc.sample_step;
+        transmittance *= ct_expf(-extinction);
+        p = add3(p, step_to_light);
+        if (transmittance * 255.f < 1.f) {
+            break;
+        }
+    }
+    out[i] = (uint8_t)(transmittance * 255.f);
+}
+
+hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream)
+{
+    const int64_t total = (int64_t)sc.nx * sc.ny * sc.nz;
+    const int threads = 256;
+    const int64_t blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(inscatter_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, sc, out);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// the estimator
+// =============================================================================================
+struct MieLds {
+    float cdf[kMieN];
+    float chopped[kMieN];
+    uint16_t guide[kGuideN + 2];
+};
+
+CT_DEV void load_tables(const DevScene &sc, MieLds &lds)
+{
+    for (int i = threadIdx.x; i < kMieN; i += blockDim.x) {
+        lds.cdf[i] = sc.cdf[i];
+        lds.chopped[i] = sc.chopped[i];
+    }
+    for (int i = threadIdx.x; i < kGuideN + 2; i += blockDim.x) {
+        lds.guide[i] = sc.guide[i];
+    }
+    __syncthreads();
+}
+
+// Primary ray of pixel (x,y): trace<>, cameraCommon.cuh:18-30.
+CT_DEV f3 primary_direction(const DevScene &sc, uint32_t x, uint32_t y)
+{
+    const float dx = (float)x / (float)sc.width * 2.f - 1.f;
+    const float dy = (float)y / (float)sc.height * 2.f - 1.f;
+    const f3 U = mk3(sc.ux, sc.uy, sc.uz), V = mk3(sc.vx, sc.vy, sc.vz), W = mk3(sc.wx, sc.wy, sc.wz);
+    return normalize3(add3(add3(scale3(U, dx), scale3(V, dy)), W));
+}
+
+// NEE: getInScattering, cloud.cuh:146-158.
+CT_DEV f3 in_scattering(const DevScene &sc, const MieLds &lds, f3 pos, f3 dir, bool chopped)
+{
+    const float cos_light = dot3(mk3(sc.nlx, sc.nly, sc.nlz), dir);
+    const float u = (cos_light + 1) / 2;
+    const float phase = chopped ? tex1(lds.chopped, u) : tex1(sc.mie, u);
+    const float ins = tex3_apron(sc, sc.icells, pos);
+    f3 l = scale3(mk3(sc.lr, sc.lg, sc.lb), ins);
+    l = scale3(l, phase);
+    return scale3(l, sc.sun_ratio);
+}
+
+enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_BOUNCE = 2 };
+
+constexpr uint32_t kChunk = 512;    // samples a wave takes from the global queue at once
+constexpr uint32_t kRegenMin = 8;   // idle lanes that trigger a regeneration phase
+
+CT_DEV uint32_t lane_rank(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Persistent wave-scheduled estimator.  Every lane owns one path at a time; a wave repeatedly
+// picks the phase (regenerate / march one step / scatter) that the most lanes are waiting
+// for, so lanes marching through empty space do not hold back lanes that collide every step
+// and finished paths are replaced immediately from a global sample queue.  Paths are
+// independent and seeded by (pixel, subframe) only, so the schedule cannot change a result.
+template <int MODE>
+__global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, BatchArgs ba)
+{
+    __shared__ MieLds lds;
+    load_tables(sc, lds);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), stepv = mk3(0, 0, 0), rad = mk3(0, 0, 0);
+    uint32_t seed = 0, depth = 0, out_idx = 0;
+    float xi = 0, T = 1;
+    int state = ST_IDLE;
+
+    // wave-uniform bookkeeping (lives in SGPRs)
+    uint32_t q_next = 0, q_end = 0;
+    bool drained = false;
+    uint32_t c_paths = 0, c_hits = 0, c_dl = 0, c_il = 0, c_cap = 0;
+
+    const f3 eye = mk3(sc.ex, sc.ey, sc.ez);
+
+    for (;;) {
+        // ---------------- regenerate ----------------
+        uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
+        uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (n_idle >= kRegenMin && !(drained && q_next == q_end)) {
+            if (q_next == q_end) {
+                uint32_t base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(ba.queue, kChunk);
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= ba.total) {
+                    drained = true;
+                } else {
+                    q_next = base;
+                    q_end = min(base + kChunk, ba.total);
+                }
+            }
+            if (q_next != q_end) {
+                const uint32_t avail = q_end - q_next;
+                const uint32_t rank = lane_rank(idle);
+                const bool take = (state == ST_IDLE) && rank < avail;
+                const uint32_t q = q_next + rank;
+                q_next += min(n_idle, avail);
+                if (take) {
+                    const uint32_t c = q >> 6, l = q & 63u;
+                    const uint32_t k = c / ba.S, s = c - k * ba.S;
+                    const uint32_t tile = ba.tiles[k];
+                    const uint32_t ty = tile / sc.tiles_x, tx = tile - ty * sc.tiles_x;
+                    const uint32_t x = tx * kTile + (l & 7u), y = ty * kTile + (l >> 3);
+                    if (x < sc.width && y < sc.height) {
+                        out_idx = (s * sc.height + y) * sc.width + x;
+                        const f3 d = primary_direction(sc, x, y);
+                        float t_hit;
+                        const bool hit = intersect_box(sc, eye, d, t_hit);
+                        c_paths += 1; // (summed per lane below; see flush)
+                        if (!hit) {
+                            ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f); // miss: progressive.cu:44-46
+                        } else {
+                            c_hits += 1;
+                            pos = add3(eye, scale3(d, t_hit));                       // :11
+                            pos = add3(pos, scale3(mk3(sc.bx, sc.by, sc.bz), 0.5f)); // :12
+                            dir = normalize3(d);                                     // :17
+                            seed = tea4(x * 4096u + y, ba.first_subframe + s);       // :21
+                            rad = mk3(0, 0, 0);
+                            depth = 0;
+                            if (MODE == 1) {
+                                dir = new_direction(lds.cdf, lds.guide, seed, dir);  // :86
+                            }
+                            // first loop test + depth bump (:28-34); mode 2 has no loop (:134)
+                            bool go = in_box(sc, pos);
+                            if (MODE != 2 && go) {
+                                depth = 1;
+                                if (depth == sc.max_depth) {
+                                    c_cap += 1;
+                                    go = false;
+                                }
+                            }
+                            if (go) {
+                                xi = u24_to_float(lcg24(seed));
+                                T = 1;
+                                stepv = scale3(dir, sc.sample_step);
+                                state = ST_MARCH;
+                            } else {
+                                ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        const uint64_t marching = __builtin_amdgcn_ballot_w64(state == ST_MARCH);
+        const uint64_t bouncing = __builtin_amdgcn_ballot_w64(state == ST_BOUNCE);
+        const uint32_t nm = (uint32_t)__builtin_popcountll(marching);
+        const uint32_t nb = (uint32_t)__builtin_popcountll(bouncing);
+        if ((marching | bouncing) == 0) {
+            if (drained && q_next == q_end) {
+                break;
+            }
+            continue; // everything idle: go regenerate (n_idle == 64 >= kRegenMin)
+        }
+
+        if (nb > nm) {
+            // ---------------- scatter: NEE + new direction (cloudRadianceMaterials.cu:53-61) ----------------
+            if (state == ST_BOUNCE) {
+                const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
+                rad = add3(rad, in_scattering(sc, lds, pos, dir, chopped));
+                c_il += 1;
+                bool go = (MODE != 2);
+                if (go) {
+                    dir = new_direction(lds.cdf, lds.guide, seed, dir);
+                    depth++;
+                    if (depth == sc.max_depth) {
+                        c_cap += 1;
+                        go = false;
+                    }
+                }
+                if (go) {
+                    xi = u24_to_float(lcg24(seed));
+                    T = 1;
+                    stepv = scale3(dir, sc.sample_step);
+                    state = ST_MARCH;
+                } else {
+                    ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                    state = ST_IDLE;
+                }
+            }
+        } else {
+            // ---------------- march one step (getNextScatteringEvent, cloud.cuh:87-105) ----------------
+            if (state == ST_MARCH) {
+                pos = add3(pos, stepv);
+                const float density = tex3_apron(sc, sc.dcells, pos) * sc.density_multiplier;
+                c_dl += 1;
+                const float extinction = density * sc.sample_step;
+                T *= expf_inrange(-extinction);
+                if (xi > T) {
+                    const float lg = ct_logf(xi / T);
+                    const float inv = 1.0f / density;
+                    pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
+                    if (in_box(sc, pos)) {
+                        state = ST_BOUNCE;
+                    } else {
+                        ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                        state = ST_IDLE;
+                    }
+                } else if (!in_box(sc, pos)) {
+                    ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                    state = ST_IDLE;
+                }
+            }
+        }
+    }
+
+    // flush counters: per-lane tallies -> one atomic per counter per wave
+    uint32_t vals[5] = { c_paths, c_hits, c_dl, c_il, c_cap };
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        uint32_t v = vals[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            v += __shfl_xor(v, off);
+        }
+        vals[i] = v;
+    }
+    if (lane == 0) {
+        atomicAdd(&ba.counters[0], (unsigned long long)vals[0]);
+        atomicAdd(&ba.counters[1], (unsigned long long)vals[1]);
+        atomicAdd(&ba.counters[2], (unsigned long long)vals[2]);
+        atomicAdd(&ba.counters[3], (unsigned long long)vals[3]);
+        atomicAdd(&ba.counters[4], (unsigned long long)vals[3]); // scatter events == NEE lookups
+        atomicAdd(&ba.counters[5], (unsigned long long)vals[4]);
+    }
+}
+
+LaunchShape persistent_shape(int device)
+{
+    hipDeviceProp_t prop;
+    LaunchShape s{ 1024, 256 };
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+        s.blocks = prop.multiProcessorCount * 4; // 4 x 256 threads per CU: LDS 40 KiB/block
+    }
+    return s;
+}
+
+hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream)
+{
+    const dim3 grid(shape.blocks), block(shape.threads);
+    switch (sc.mode) {
+    case 0:
+        hipLaunchKernelGGL(render_persistent_kernel<0>, grid, block, 0, stream, sc, ba);
+        break;
+    case 1:
+        hipLaunchKernelGGL(render_persistent_kernel<1>, grid, block, 0, stream, sc, ba);
+        break;
+    default:
+        hipLaunchKernelGGL(render_persistent_kernel<2>, grid, block, 0, stream, sc, ba);
+        break;
+    }
+    return hipGetLastError();
+}
+
+// One thread per pixel of one subframe, the reference's control flow verbatim (nested loops).
+// Kept as an independent second implementation on the GPU (tests cross-check it against the
+// persistent kernel and the oracle) and as the divergence baseline in bench_kernels.
+__global__ __launch_bounds__(256) void render_simple_kernel(DevScene sc, BatchArgs ba, uint32_t shard_index,
+                                                            uint32_t shard_count)
+{
+    __shared__ MieLds lds;
+    load_tables(sc, lds);
+    const uint32_t tile = blockIdx.x / 4u; // 4 waves per block, one 8x8 tile per wave
+    const uint32_t wave = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const uint32_t tile_id = blockIdx.x * 4u + wave;
+    (void)tile;
+    if (tile_id >= sc.tiles_x * sc.tiles_y) {
+        return;
+    }
+    const uint32_t ty = tile_id / sc.tiles_x, tx = tile_id - ty * sc.tiles_x;
+    if (tile_owner(tx, ty, shard_count) != shard_index) {
+        return;
+    }
+    const uint32_t x = tx * kTile + (l & 7u), y = ty * kTile + (l >> 3);
+    if (x >= sc.width || y >= sc.height) {
+        return;
+    }
+    const uint32_t out_idx = y * sc.width + x;
+    uint32_t c_hits = 0, c_dl = 0, c_il = 0, c_cap = 0;
+    f3 rad = mk3(0, 0, 0);
+    const f3 eye = mk3(sc.ex, sc.ey, sc.ez);
+    const f3 d = primary_direction(sc, x, y);
+    float t_hit;
+    if (intersect_box(sc, eye, d, t_hit)) {
+        c_hits = 1;
+        f3 pos = add3(eye, scale3(d, t_hit));
+        pos = add3(pos, scale3(mk3(sc.bx, sc.by, sc.bz), 0.5f));
+        f3 dir = normalize3(d);
+        uint32_t seed = tea4(x * 4096u + y, ba.first_subframe);
+        if (sc.mode == 1) {
+            dir = new_direction(lds.cdf, lds.guide, seed, dir);
+        }
+        uint32_t depth = 0;
+        while (in_box(sc, pos)) {
+            if (sc.mode != 2) {
+                depth++;
+                if (depth == sc.max_depth) {
+                    c_cap = 1;
+                    break;
+                }
+            }
+            const float xi = u24_to_float(lcg24(seed));
+            const f3 stepv = scale3(dir, sc.sample_step);
+            float T = 1;
+            bool scattered = false;
+            while (in_box(sc, pos)) {
+                pos = add3(pos, stepv);
+                const float density = tex3_apron(sc, sc.dcells, pos) * sc.density_multiplier;
+                c_dl++;
+                const float extinction = density * sc.sample_step;
+                T *= ct_expf(-extinction);
+                if (xi > T) {
+                    scattered = true;
+                    const float lg = ct_logf(xi / T);
+                    const float inv = 1.0f / density;
+                    pos = sub3(pos, scale3(scale3(dir, lg), inv));
+                    break;
+                }
+            }
+            if (!scattered || !in_box(sc, pos)) {
+                break;
+            }
+            const bool chopped = (sc.mode == 1) ? true : (sc.mode == 0 ? (depth != 1) : false);
+            rad = add3(rad, in_scattering(sc, lds, pos, dir, chopped));
+            c_il++;
+            if (sc.mode == 2) {
+                break;
+            }
+            dir = new_direction(lds.cdf, lds.guide, seed, dir);
+        }
+    }
+    ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+    atomicAdd(&ba.counters[0], 1ull);
+    atomicAdd(&ba.counters[1], (unsigned long long)c_hits);
+    atomicAdd(&ba.counters[2], (unsigned long long)c_dl);
+    atomicAdd(&ba.counters[3], (unsigned long long)c_il);
+    atomicAdd(&ba.counters[4], (unsigned long long)c_il);
+    atomicAdd(&ba.counters[5], (unsigned long long)c_cap);
+}
+
+hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_t shard_index,
+                                uint32_t shard_count, hipStream_t stream)
+{
+    const uint32_t tiles = sc.tiles_x * sc.tiles_y;
+    hipLaunchKernelGGL(render_simple_kernel, dim3((tiles + 3) / 4), dim3(256), 0, stream, sc, ba, shard_index,
+                       shard_count);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// progressive accumulation (progressive.cu:17-27) of S consecutive subframes, in order.
+// Only this shard's pixels are touched; everything else stays exactly 0 so that a sum over
+// shards (RCCL) reproduces the single-GPU image bit for bit.
+// =============================================================================================
+__global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__restrict__ frames,
+                                                               float4 *__restrict__ mean, float4 *__restrict__ m2,
+                                                               uint32_t first_subframe, uint32_t S, uint32_t width,
+                                                               uint32_t height, uint32_t shard_index,
+                                                               uint32_t shard_count)
+{
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
+    const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= width || y >= height) {
+        return;
+    }
+    if (tile_owner(x / kTile, y / kTile, shard_count) != shard_index) {
+        return;
+    }
+    const size_t pix = (size_t)y * width + x;
+    const size_t plane = (size_t)width * height;
+    float4 mu = mean[pix], var = m2[pix];
+    for (uint32_t s = 0; s < S; s++) {
+        const float4 nr = frames[s * plane + pix];
+        const float w = 1.0f / (float)(first_subframe + s);
+        float4 nm;
+        nm.x = mu.x + (nr.x - mu.x) * w;
+        nm.y = mu.y + (nr.y - mu.y) * w;
+        nm.z = mu.z + (nr.z - mu.z) * w;
+        nm.w = mu.w + (nr.w - mu.w) * w;
+        var.x = var.x + (nr.x - mu.x) * (nr.x - nm.x);
+        var.y = var.y + (nr.y - mu.y) * (nr.y - nm.y);
+        var.z = var.z + (nr.z - mu.z) * (nr.z - nm.z);
+        var.w = var.w + (nr.w - mu.w) * (nr.w - nm.w);
+        mu = nm;
+    }
+    mean[pix] = mu;
+    m2[pix] = var;
+}
+
+hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
+                                   uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
+                                   uint32_t shard_count, hipStream_t stream)
+{
+    const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
+    hipLaunchKernelGGL(accumulate_batch_kernel, grid, block, 0, stream, frames, mean, m2, first_subframe, S, width,
+                       height, shard_index, shard_count);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// Reinhard tonemap (reinhard.cu:20-84).  The summation ORDER is part of the result, so the
+// column sums run y = 0..H-1 in one thread per column and the final sum runs over the columns
+// in order in one lane, exactly like firstPass / secondPass.
+// =============================================================================================
+CT_DEV float luminance4(float4 c)
+{
+    return c.x * 0.265068f + c.y * 0.67023428f + c.z * 0.06409157f + c.w * 0.0f;
+}
+
+__global__ void reinhard_columns_kernel(const float4 *__restrict__ mean, uint32_t width, uint32_t height,
+                                        float *__restrict__ column_sums)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width) {
+        return;
+    }
+    const float DELTA = 0.00001f;
+    float sum = 0;
+    for (uint32_t y = 0; y < height; y++) {
+        sum += luminance4(mean[(size_t)y * width + x]) + DELTA;
+    }
+    column_sums[x] = sum;
+}
+
+__global__ void reinhard_average_kernel(const float *__restrict__ column_sums, uint32_t width, uint32_t total_pixels,
+                                        float *__restrict__ avg)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float result = 0;
+        for (uint32_t i = 0; i < width; i++) {
+            result += column_sums[i];
+        }
+        avg[0] = result / (float)total_pixels;
+    }
+}
+
+__global__ void reinhard_apply_kernel(const float4 *__restrict__ mean, uint32_t pixels, float exposure,
+                                      const float *__restrict__ avg, uchar4 *__restrict__ screen)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixels) {
+        return;
+    }
+    const float4 color = mean[i];
+    const float lw = luminance4(color);
+    float ld = lw * exposure / avg[0];
+    ld = ld / (1.f + ld);
+    const float sc = ld / lw;
+    const float inv_gamma = 1.f / 2.2f;
+    // optix clamp(f,0,1) = fmaxf(0, fminf(f,1)): the NaN of black pixels becomes 1
+    float r = fmaxf(0.f, fminf(color.x * sc, 1.f));
+    float g = fmaxf(0.f, fminf(color.y * sc, 1.f));
+    float b = fmaxf(0.f, fminf(color.z * sc, 1.f));
+    r = ct_powf(r, inv_gamma) * 255;
+    g = ct_powf(g, inv_gamma) * 255;
+    b = ct_powf(b, inv_gamma) * 255;
+    screen[i] = make_uchar4((unsigned char)r, (unsigned char)g, (unsigned char)b, 255);
+}
+
+hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure, float *column_sums,
+                           float *avg, uchar4 *screen, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reinhard_columns_kernel, dim3((width + 63) / 64), dim3(64), 0, stream, mean, width, height,
+                       column_sums);
+    hipLaunchKernelGGL(reinhard_average_kernel, dim3(1), dim3(64), 0, stream, column_sums, width, width * height,
+                       avg);
+    const uint32_t pixels = width * height;
+    hipLaunchKernelGGL(reinhard_apply_kernel, dim3((pixels + 255) / 256), dim3(256), 0, stream, mean, pixels,
+                       exposure, avg, screen);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// Camera::isConverged (Camera.cpp:232-268), channel x only; counts pixels outside the interval.
+// =============================================================================================
+__global__ void converged_kernel(const float4 *__restrict__ mean, const float4 *__restrict__ m2,
+                                 uint32_t subframe_id, uint64_t pixels, unsigned long long *unconverged)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < pixels) {
+        const float N = (float)subframe_id;
+        const float sigma = sqrtf(m2[i].x / N);
+        const float abs_ci = 1.96f * sigma / sqrtf(N);
+        const float rel_ci = abs_ci / (mean[i].x + 1.1920929e-07f);
+        bad = !(rel_ci < 0.02f || abs_ci < 1e-2f);
+    }
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(bad);
+    if ((threadIdx.x & 63u) == 0 && mask != 0) {
+        atomicAdd(unconverged, (unsigned long long)__builtin_popcountll(mask));
+    }
+}
+
+hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,
+                            unsigned long long *unconverged, hipStream_t stream)
+{
+    hipLaunchKernelGGL(converged_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, mean, m2,
+                       subframe_id, pixels, unconverged);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// self-test hook: k(val) of the guide-table CDF inversion for a range of 24-bit randoms
+// =============================================================================================
+__global__ void cdf_selftest_kernel(const float *__restrict__ cdf, const uint16_t *__restrict__ guide,
+                                    uint32_t first_u24, uint32_t count, uint32_t *__restrict__ k_out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) {
+        return;
+    }
+    const float c = sample_cos_theta(cdf, guide, first_u24 + i);
+    // cos = (2k+1)/65536 - 1  ->  k
+    k_out[i] = ((uint32_t)((c + 1.0f) * 65536.0f) - 1u) >> 1;
+}
+
+hipError_t launch_cdf_selftest(const float *cdf, const uint16_t *guide, uint32_t first_u24, uint32_t count,
+                               uint32_t *k_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(cdf_selftest_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, cdf, guide, first_u24,
+                       count, k_out);
+    return hipGetLastError();
+}
+
+} // namespace ct

@@ -1,0 +1,263 @@
+/*
+ * cloudtrace.h -- C ABI of libcloudtrace.so, the MI355X (gfx950) replacement for
+ * the Monte-Carlo cloud radiance estimator of marsermd/DeepestScatter.
+ *
+ * The reference hides its estimator behind the `ARenderer` plug-in interface
+ *     class ARenderer { getCamera(); init(); render(optix::Buffer frameResultBuffer); }
+ *     (src/Scene/Cameras/ARenderer.h:6-16, implementation PathTracingRenderer.cpp:14-31)
+ * whose real "signature" is the set of OptiX context variables the device
+ * programs read.  That interface is OptiX-typed and cannot
+ * be kept literally; this header keeps its three verbs and makes the implicit
+ * inputs explicit.  Every entry point cites the reference code it replaces.
+ * "src/" below = DeepestScatter_DataGen/DeepestScatter_DataGen/src/.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, PODs.  No C++/torch/HIP types in signatures.
+ *   - every function returns 0 (CT_OK) or a negative CtStatus; nothing throws,
+ *     nothing calls exit().  ct_last_error() gives the message of the last
+ *     failure on that handle (or of the last failed ct_create when h == NULL).
+ *   - a handle is NOT thread-safe (the reference is single-threaded:
+ *     GuiExecutionLoop.cpp:53-60); distinct handles are independent.
+ *   - image layout: row-major W x H, 4 floats (or 4 bytes) per pixel, row 0 is the
+ *     BOTTOM of the picture (cameraCommon.cuh:22-25).
+ *   - pointers named *_dev are device pointers valid on the handle's GPU,
+ *     pointers named *_host are host pointers; `ct_download` copies device->host.
+ *   - all device work is issued on one HIP stream owned by the handle (or the one
+ *     given with ct_set_stream) and the *_async-free entry points return after
+ *     that stream is idle.
+ */
+#ifndef CLOUDTRACE_H
+#define CLOUDTRACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CT_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define CT_API __attribute__((visibility("default")))
+#else
+#define CT_API
+#endif
+
+typedef enum CtStatus {
+    CT_OK = 0,
+    CT_E_INVAL = -1,   /* bad argument (std::invalid_argument in CloudMaterial.cpp:62) */
+    CT_E_HIP = -2,     /* a HIP call or kernel failed (optix::Exception path, main.cpp:65-69) */
+    CT_E_NOMEM = -3,   /* host or device allocation failed */
+    CT_E_STATE = -4,   /* call order violated (e.g. render before ct_set_camera) */
+    CT_E_NODEVICE = -5 /* no usable gfx950 device / extension missing */
+} CtStatus;
+
+/* Cloud::Rendering::Mode, src/Scene/SceneDescription.h:39-44 -> program chosen in
+ * CloudMaterial.cpp:51-64 */
+typedef enum CtMode {
+    CT_MODE_SUN_AND_SKY_ALL_SCATTER = 0, /* totalRadiance,              cloudRadianceMaterials.cu:9-66  */
+    CT_MODE_SUN_MULTIPLE_SCATTER = 1,    /* multipleScatterSunRadiance, cloudRadianceMaterials.cu:72-115 */
+    CT_MODE_SUN_SINGLE_SCATTER = 2       /* singleScatterSunRadiance,   cloudRadianceMaterials.cu:120-148 */
+} CtMode;
+
+/* Free-flight sampler. MARCH is the reference's estimator (cloud.cuh:77-114);
+ * DELTA is Woodcock tracking over per-brick majorants (BASELINE.json north_star). */
+typedef enum CtEstimator {
+    CT_EST_MARCH = 0,
+    CT_EST_DELTA = 1
+} CtEstimator;
+
+/* Which buffer ct_download / ct_device_ptr refers to. */
+typedef enum CtBuffer {
+    CT_BUF_MEAN = 0,       /* progressiveBuffer  float4 W*H   (Camera.cpp:46)        */
+    CT_BUF_M2 = 1,         /* varianceBuffer     float4 W*H   (Camera.cpp:47)        */
+    CT_BUF_FRAME = 2,      /* frameResultBuffer  float4 W*H   (Camera.cpp:45)        */
+    CT_BUF_SCREEN = 3,     /* screenBuffer       uchar4 W*H   (Camera.cpp:48)        */
+    CT_BUF_INSCATTER = 4,  /* inScatterBuffer    uint8  X*Y*Z (VDBCloud.cpp:70)      */
+    CT_BUF_DENSITY = 5     /* density            uint8  X*Y*Z (Resources.cpp:127-141)*/
+} CtBuffer;
+
+/*
+ * Everything the reference's device programs read from OptiX variable scopes,
+ * as one POD (SURVEY.md section 8b "implicit inputs").
+ */
+typedef struct CtScene {
+    uint32_t abi_version;     /* must be CT_ABI_VERSION */
+
+    /* --- density texture: Resources::loadVolumeBuffer, src/Util/Resources.cpp:68-155 --- */
+    uint32_t dims[3];         /* X,Y,Z texels, INCLUDING the 1-texel zero border (:97-101) */
+    const uint8_t *density_host; /* X*Y*Z bytes, x fastest, z slowest (:127-141); copied at create */
+
+    /* --- Cloud::Model, src/Scene/SceneDescription.h:60-83 --- */
+    float cloud_size_m;       /* 7000 in main.cpp:63 */
+    float mean_free_path_m;   /* 10, SceneDescription.h:80; densityMultiplier = size/mfp (VDBCloud.cpp:109) */
+
+    /* --- Cloud::Rendering, SceneDescription.h:35-57; installers.cpp:86 --- */
+    float sample_step;        /* 1/512 */
+    int32_t mode;             /* CtMode */
+    int32_t estimator;        /* CtEstimator */
+    uint32_t max_depth;       /* MAX_DEPTH = 2000, cloudRadianceMaterials.cu:4 */
+
+    /* --- DirectionalLight, SceneDescription.h:13-26; Sun.cpp:13-18; installers.cpp:74-101 --- */
+    float light_direction[3]; /* direction the light TRAVELS; normalised twice like the reference */
+    float light_color[3];     /* (1,1,1) */
+    float light_intensity;    /* 1e6 */
+
+    /* --- Camera::Settings, src/Scene/Cameras/Camera.h:20-28 --- */
+    uint32_t width, height;
+
+    /* --- Mie tables: Scene::init binds them (Scene.cpp:38-40); data of Mie.cpp:8-8203 --- */
+    const float *mie_host;         /* raw `mie` table,        mie_count floats */
+    const float *chopped_mie_host; /* raw `choppedMie` table, mie_count floats */
+    uint32_t mie_count;            /* 4096 */
+
+    /* --- placement (new: the reference is single-GPU) --- */
+    int32_t device;           /* HIP device ordinal this handle lives on */
+    uint32_t shard_index;     /* this handle renders the 8x8-pixel tiles (tx,ty) with        */
+    uint32_t shard_count;     /*   ct_tile_owner(tx,ty,shard_count) == shard_index; 1 = all  */
+
+    uint32_t flags;           /* CT_FLAG_* */
+} CtScene;
+
+#define CT_FLAG_NONE 0u
+#define CT_FLAG_SIMPLE_KERNEL 1u /* one thread per pixel, nested loops (A/B + cross-check only) */
+
+/* Deterministic work counters of everything rendered since create/ct_reset
+ * (the algorithmic-bytes figure is built from these). */
+typedef struct CtCounters {
+    uint64_t paths;            /* primary rays traced (pixels x subframes in this shard) */
+    uint64_t box_hits;         /* primary rays that hit the cloud's box */
+    uint64_t density_lookups;  /* trilinear fetches of the density texture (8 B each) */
+    uint64_t inscatter_lookups;/* trilinear fetches of the shadow volume   (8 B each) */
+    uint64_t scatter_events;   /* accepted collisions = NEE evaluations */
+    uint64_t depth_capped;     /* paths stopped by max_depth */
+} CtCounters;
+
+typedef struct CtHandle_ *CtHandle;
+
+/* ---- lifetime --------------------------------------------------------------------- */
+
+/* Scene::init for the path-tracing configuration (Scene.cpp:36-46): uploads density,
+ * prepares the three Mie textures (Mie.cpp:8206-8297), publishes the Sun/VDBCloud
+ * variables (Sun.cpp:13-18, VDBCloud.cpp:88-117), runs the inScatter precompute
+ * (VDBCloud.cpp:57-86 -> inScatter.cu:40-66), allocates frame/progressive/variance/
+ * screen buffers and clears them (Camera.cpp:45-48,77-86).  Sets the default camera
+ * pose of Camera.cpp:37-39. */
+CT_API int ct_create(const CtScene *scene, CtHandle *out);
+
+/* Context destruction between tasks, GuiExecutionLoop.cpp:93-97. NULL is a no-op. */
+CT_API int ct_destroy(CtHandle h);
+
+/* Message of the last failure (UTF-8, owned by the library, valid until the next call
+ * on the same handle).  h == NULL: last failure of ct_create in this thread. */
+CT_API const char *ct_last_error(CtHandle h);
+
+/* Use `hip_stream` (a hipStream_t passed as void*) for all later work on this handle
+ * instead of the handle's own stream.  NULL restores the handle's stream. */
+CT_API int ct_set_stream(CtHandle h, void *hip_stream);
+
+/* ---- ARenderer verbs ----------------------------------------------------------------- */
+
+/* ARenderer::getCamera()["eye"|"U"|"V"|"W"]->setFloat(...)   Camera.cpp:126-133 */
+CT_API int ct_set_camera(CtHandle h, const float eye[3], const float U[3], const float V[3], const float W[3]);
+
+/* ARenderer::render(frameResultBuffer) after context["subframeId"]=id  (Camera.cpp:191-195,
+ * PathTracingRenderer.cpp:21-31): one path per pixel, result float4(r,g,b,1) per pixel into
+ * the handle's frame buffer; if frame_rgba_dev != NULL the frame is also copied there
+ * (device pointer, W*H*4 floats, caller-owned).  Pixels of other shards are written as 0
+ * with alpha 0.  Seeds are tea<4>(x*4096+y, subframe_id)  (documented deviation from
+ * random.cuh:38, which mixes in clock()). */
+CT_API int ct_render_subframe(CtHandle h, uint32_t subframe_id, float *frame_rgba_dev);
+
+/* updateFrameResult, progressive.cu:17-27, launched by Camera.cpp:197-199: Welford update
+ * of mean/M2 with n = subframe_id from the handle's frame buffer (or from frame_rgba_dev
+ * when not NULL). */
+CT_API int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *frame_rgba_dev);
+
+/* The hot path of Camera::render's loop (Camera.cpp:189-200) fused: for id = first ..
+ * first+count-1 { render(id); updateFrameResult(id) } with identical results, in one launch,
+ * without materialising the frame buffer.  Requires first == (subframes accumulated so far)+1. */
+CT_API int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint32_t count);
+
+/* Camera::reset, Camera.cpp:77-86 (clearScreen, progressive.cu:29-34): zero frame, mean, M2,
+ * subframe count.  Counters are zeroed too. */
+CT_API int ct_reset(CtHandle h);
+
+/* Reinhard tonemap of the running mean: firstPass/secondPass/applyReinhard,
+ * reinhard.cu:26-84, launched by Camera.cpp:202-210; default exposure 0.4 (Camera.h:90).
+ * Result goes to the handle's screen buffer and, if rgba_host != NULL, is copied to the host
+ * (W*H*4 bytes). avg_luminance_out (optional) receives reinhard.cu:53 averageLuminance. */
+CT_API int ct_tonemap(CtHandle h, float exposure, uint8_t *rgba_host, float *avg_luminance_out);
+
+/* Camera::isConverged, Camera.cpp:232-268, evaluated on the device.  *converged_out = 1 when
+ * fewer than 500 pixels are outside the 95 % interval; *unconverged_pixels_out optional. */
+CT_API int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unconverged_pixels_out);
+
+/* ---- data access -------------------------------------------------------------------- */
+
+/* BufferBind<T>(buffer) map/copy, src/Util/BufferBind.h:11-74 (e.g. Camera.cpp:161,239-240).
+ * Copies the whole buffer to dst_host; dst_bytes must equal ct_buffer_bytes(). */
+CT_API int ct_download(CtHandle h, int32_t which /*CtBuffer*/, void *dst_host, size_t dst_bytes);
+CT_API int ct_buffer_bytes(CtHandle h, int32_t which /*CtBuffer*/, size_t *bytes_out);
+
+/* Raw device pointer of CT_BUF_MEAN / CT_BUF_M2 / CT_BUF_FRAME / CT_BUF_SCREEN, so a caller can
+ * hand the accumulated radiance buffer to a collective (RCCL) without a copy. */
+CT_API int ct_device_ptr(CtHandle h, int32_t which /*CtBuffer*/, void **ptr_out);
+
+/* Device-to-device copy of a whole buffer into caller-owned device memory (e.g. a tensor that a
+ * collective will reduce), on the handle's stream; returns after the copy completed. */
+CT_API int ct_copy_to_device(CtHandle h, int32_t which /*CtBuffer*/, void *dst_dev, size_t dst_bytes);
+
+/* Number of subframes accumulated (Camera::subframeId, Camera.h:76). */
+CT_API int ct_subframes(CtHandle h, uint32_t *count_out);
+
+/* After an external reduction wrote merged data into CT_BUF_MEAN/CT_BUF_M2 (multi-GPU frame
+ * reduce), tell the handle how many subframes those buffers now represent. */
+CT_API int ct_set_subframes(CtHandle h, uint32_t count);
+
+CT_API int ct_counters(CtHandle h, CtCounters *out);
+
+/* Milliseconds the GPU spent in the estimator kernel and in the accumulate kernel since
+ * create/reset, measured with HIP events on the handle's stream, and the number of estimator
+ * launches.  Any pointer may be NULL. */
+CT_API int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_ms_out, uint64_t *launches_out);
+
+/* Self-test hook: k(val) of the CDF inversion (cloud.cuh:162-180) for `count` consecutive 24-bit
+ * random integers starting at first_u24, evaluated by the device code; cos(theta) = (2k+1)/65536-1. */
+CT_API int ct_debug_cdf_inversion(CtHandle h, uint32_t first_u24, uint32_t count, uint32_t *k_host_out);
+
+/* ---- host-side helpers of the same path (pure CPU, no handle, no GPU) ------------------- */
+
+/* sutil::calculateCameraVariables(..., fov_is_vertical=false), src/Util/sutil.cpp:501-524, as
+ * called by Camera::updatePosition (Camera.cpp:100-134): hfov in degrees. */
+CT_API int ct_calculate_camera_variables(const float eye[3], const float lookat[3], const float up[3],
+                                  float hfov_deg, float aspect_ratio,
+                                  float U_out[3], float V_out[3], float W_out[3]);
+
+/* The quantiser of Resources::loadVolumeBuffer, Resources.cpp:92-141: payload float grid
+ * (nx*ny*nz, x fastest) -> uint8 texture of (nx+2)(ny+2)(nz+2) with a 1-texel zero border,
+ * value = (uint8)(v / max * 255) computed in double, truncating. */
+CT_API int ct_quantize_volume(const float *grid_host, const uint32_t payload_dims[3], uint8_t *texture_host_out);
+
+/* Resources::generateMipmaps, Resources.cpp:169-209: level count = floor(log2(maxdim))+1; each
+ * level is the 2x2x2 integer mean (uint16 sum / 8, zero outside).  level_offsets_out[l] = byte
+ * offset of level l in `pyramid_host_out`; returns CT_E_INVAL if capacity is too small.  Pass
+ * pyramid_host_out == NULL to query *levels_out and *bytes_out. */
+CT_API int ct_generate_mipmaps(const uint8_t *level0_host, const uint32_t dims[3],
+                        uint8_t *pyramid_host_out, size_t capacity,
+                        uint32_t *levels_out, size_t *bytes_out, size_t *level_offsets_out /*[32]*/);
+
+/* The pixel-tile -> shard map used for multi-GPU sharding: the frame is cut
+ * into 8x8-pixel tiles; tile (tx,ty) belongs to shard (tx + 3*ty) mod shard_count, a skewed
+ * interleave that gives every GPU the same mix of cloud and background. */
+CT_API uint32_t ct_tile_owner(uint32_t tile_x, uint32_t tile_y, uint32_t shard_count);
+
+/* Synthetic cloud of SURVEY section 8(d): 5-octave gradient-noise fBm x ellipsoidal falloff,
+ * thresholded, quantised by ct_quantize_volume's rule into an n^3 texture (payload n-2). */
+CT_API int ct_make_procedural_cloud(uint32_t n, uint32_t seed, uint8_t *texture_host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOUDTRACE_H */

@@ -1,0 +1,802 @@
+/*
+ * ct_oracle.c -- CPU ORACLE: a plain-C restatement of the reference's cloud radiance
+ * estimator (marsermd/DeepestScatter, DataGen).  TEST INFRASTRUCTURE ONLY.
+ *
+ *   * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *     The product (libcloudtrace.so, deepestscatter_amd/) never includes, links or calls it.
+ *   * PARITY UNPINNED: the reference ships no tests, golden vectors or assets (SURVEY.md
+ *     section 4) and cannot be built here (OptiX 5.1 / CUDA 9.2 device programs; SURVEY.md
+ *     section 8c), so this restatement is checked only against closed-form answers
+ *     (tests/test_oracle_*.py) and against goldens it produced itself (tests/golden/).
+ *   * Each function cites the reference lines it follows.  "src/" =
+ *     DeepestScatter_DataGen/DeepestScatter_DataGen/src/.
+ *
+ * Third-party arithmetic the reference leans on and that is not in its tree is restated
+ * from the published definitions:
+ *   - NVIDIA OptiX SDK 5.1.0 optixu_math_namespace.h: normalize (v * (1/sqrtf(dot))), dot,
+ *     cross, float3/float (multiply by reciprocal), clamp(f,a,b)=fmaxf(a,fminf(f,b)), Onb.
+ *   - CUDA texture unit: unnormalised coordinate x = u*N - 0.5, i = floor(x), weight
+ *     frac(x), clamp-to-edge on i and i+1, uchar -> float /255 (cudaReadModeNormalizedFloat).
+ *     Our spec uses exact float weights (hardware uses 8-bit fixed point) and evaluates
+ *     lerp(a,b,t) = fmaf(t, b-a, a), x first, then y, then z.
+ *   - CUDA libm (expf/log/sin/cos/powf under --use_fast_math): replaced by the
+ *     deterministic functions of include/ct_fmath.h (the numeric contract shared with the
+ *     HIP kernels so that a path takes identical branches on both sides).
+ *
+ * Documented deviation: the reference seeds with tea<4>(pixel) where v1 = clock()
+ * (random.cuh:38) -- irreproducible.  Here v1 = subframeId (NVIDIA's original two-argument
+ * tea), as SURVEY.md section 8(a9) prescribes.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/ct_fmath.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 v3_make(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v3_mul(v3 a, v3 b) { return v3_make(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
+static inline v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
+static inline float v3_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 v3_cross(v3 a, v3 b)
+{
+    return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* optix::normalize: v * (1.0f / sqrtf(dot(v, v))) */
+static inline v3 v3_normalize(v3 a)
+{
+    const float inv = 1.0f / sqrtf(v3_dot(a, a));
+    return v3_scale(a, inv);
+}
+/* optix float3 / float: multiply by the reciprocal */
+static inline v3 v3_div(v3 a, float s)
+{
+    const float inv = 1.0f / s;
+    return v3_scale(a, inv);
+}
+
+#define ORC_PI_F 3.14159265358979323846f
+
+/* ------------------------------------------------------------------------------------------
+ * RNG: src/CUDA/random.cuh:34-70.  tea<4>, 24-bit LCG, rnd in [0,1).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API uint32_t orc_tea4(uint32_t val0, uint32_t val1)
+{
+    uint32_t v0 = val0, v1 = val1, s0 = 0;
+    for (int n = 0; n < 4; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+
+ORC_API uint32_t orc_lcg(uint32_t *prev)
+{
+    *prev = 1664525u * (*prev) + 1013904223u;
+    return *prev & 0x00FFFFFFu;
+}
+
+ORC_API float orc_rnd(uint32_t *prev)
+{
+    return (float)orc_lcg(prev) / (float)0x01000000;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Mie textures: src/Mie.cpp:8206-8243 (phase / mean), :8245-8282 (running-sum CDF).
+ * float32 running sums in index order.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_mie_phase_texture(const float *raw, uint32_t cnt, float *out)
+{
+    float average = 0;
+    for (uint32_t i = 0; i < cnt; i++) {
+        average += raw[i];
+    }
+    average /= (float)cnt;
+    for (uint32_t i = 0; i < cnt; i++) {
+        out[i] = raw[i] / average;
+    }
+}
+
+ORC_API void orc_mie_integral_texture(const float *raw, uint32_t cnt, float *out)
+{
+    float sum = 0;
+    for (uint32_t i = 0; i < cnt; i++) {
+        sum += raw[i];
+    }
+    float integral = 0;
+    for (uint32_t i = 0; i < cnt; i++) {
+        integral += raw[i] / sum;
+        out[i] = integral;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Texture units (CUDA semantics restated, see header).
+ * ------------------------------------------------------------------------------------------ */
+static inline int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
+/* Filter weight: frac(x) = x - floor(x), kept strictly below 1 (a tiny negative x would
+ * otherwise round to 1.0f); this is also what gfx950's v_fract_f32 returns. */
+static inline float fracf(float x, float fl) { return fminf(x - fl, 0x1.fffffep-1f); }
+
+/* tex1D on a float buffer: linear, clamp, normalised coords (Mie.cpp:8229-8240). */
+ORC_API float orc_tex1d(const float *t, uint32_t n, float u)
+{
+    const float x = fmaf(u, (float)n, -0.5f);
+    const float fl = floorf(x);
+    const float w = fracf(x, fl);
+    const int32_t i = (int32_t)fl;
+    const float a = t[clampi(i, 0, (int32_t)n - 1)];
+    const float b = t[clampi(i + 1, 0, (int32_t)n - 1)];
+    return lerpf(a, b, w);
+}
+
+typedef struct {
+    const uint8_t *texels;
+    int32_t nx, ny, nz;
+    float sx, sy, sz; /* box coordinate -> texel coordinate: textureScale * N, in float */
+} Tex3;
+
+/* tex3D / rtTex3D on a uchar buffer with cudaReadModeNormalizedFloat, linear, clamp,
+ * normalised coords (VDBCloud.cpp:119-137; cloud.cuh:58-68).  `p` is the box-space position;
+ * the texel coordinate is p * (textureScale * N) - 0.5 with the product folded on the host. */
+static inline float tex3_fetch(const Tex3 *t, v3 p)
+{
+    const float x = fmaf(p.x, t->sx, -0.5f);
+    const float y = fmaf(p.y, t->sy, -0.5f);
+    const float z = fmaf(p.z, t->sz, -0.5f);
+    const float flx = floorf(x), fly = floorf(y), flz = floorf(z);
+    const float wx = fracf(x, flx), wy = fracf(y, fly), wz = fracf(z, flz);
+    const int32_t ix = (int32_t)flx, iy = (int32_t)fly, iz = (int32_t)flz;
+    const int32_t x0 = clampi(ix, 0, t->nx - 1), x1 = clampi(ix + 1, 0, t->nx - 1);
+    const int32_t y0 = clampi(iy, 0, t->ny - 1), y1 = clampi(iy + 1, 0, t->ny - 1);
+    const int32_t z0 = clampi(iz, 0, t->nz - 1), z1 = clampi(iz + 1, 0, t->nz - 1);
+    const size_t sy_ = (size_t)t->nx, sz_ = (size_t)t->nx * (size_t)t->ny;
+    const uint8_t *b = t->texels;
+    const float t000 = (float)b[z0 * sz_ + y0 * sy_ + x0], t100 = (float)b[z0 * sz_ + y0 * sy_ + x1];
+    const float t010 = (float)b[z0 * sz_ + y1 * sy_ + x0], t110 = (float)b[z0 * sz_ + y1 * sy_ + x1];
+    const float t001 = (float)b[z1 * sz_ + y0 * sy_ + x0], t101 = (float)b[z1 * sz_ + y0 * sy_ + x1];
+    const float t011 = (float)b[z1 * sz_ + y1 * sy_ + x0], t111 = (float)b[z1 * sz_ + y1 * sy_ + x1];
+    const float c00 = lerpf(t000, t100, wx), c10 = lerpf(t010, t110, wx);
+    const float c01 = lerpf(t001, t101, wx), c11 = lerpf(t011, t111, wx);
+    const float c0 = lerpf(c00, c10, wy), c1 = lerpf(c01, c11, wy);
+    return lerpf(c0, c1, wz) * (1.0f / 255.0f);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Scene block: the OptiX variable scopes of the path, flattened.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct OrcScene {
+    uint32_t dims[3];
+    const uint8_t *density;    /* X*Y*Z, x fastest (Resources.cpp:127-141) */
+    const uint8_t *inscatter;  /* X*Y*Z, result of orc_inscatter */
+    float cloud_size_m;        /* main.cpp:63 */
+    float mean_free_path_m;    /* SceneDescription.h:80 */
+    float sample_step;         /* installers.cpp:86 */
+    int32_t mode;              /* 0 totalRadiance, 1 multipleScatterSunRadiance, 2 singleScatterSunRadiance */
+    uint32_t max_depth;        /* cloudRadianceMaterials.cu:4 */
+    float light_direction[3];  /* as given by the user; normalised twice below */
+    float light_color[3];
+    float light_intensity;
+    uint32_t width, height;
+    float eye[3], U[3], V[3], W[3];
+    const float *mie_tex;          /* orc_mie_phase_texture(mie) */
+    const float *chopped_mie_tex;  /* orc_mie_phase_texture(choppedMie) */
+    const float *chopped_cdf_tex;  /* orc_mie_integral_texture(choppedMie) */
+    uint32_t mie_count;
+} OrcScene;
+
+typedef struct OrcCounters {
+    uint64_t paths, box_hits, density_lookups, inscatter_lookups, scatter_events, depth_capped;
+} OrcCounters;
+
+/* Derived uniforms: VDBCloud::setupVolumeVariables (VDBCloud.cpp:98-111), Sun::init
+ * (Sun.cpp:13-18), DirectionalLight ctor (SceneDescription.h:15-16) after
+ * installSceneSetup's normalize (installers.cpp:74-78). */
+typedef struct {
+    v3 bbox;           /* bboxSize = dims / maxDim */
+    v3 tscale;         /* textureScale = maxDim / dims */
+    float density_multiplier;
+    float sample_step;
+    v3 light_dir;      /* twice-normalised travel direction */
+    v3 light_rgb;      /* lightColor * lightIntensity */
+    float sun_ratio;   /* sunToSphereAreaRatio, cloud.cuh:148-151 */
+    Tex3 density, inscatter;
+    const float *mie, *chopped, *cdf;
+    uint32_t mie_n;
+    uint32_t max_depth;
+    int32_t mode;
+} Ctx;
+
+static void ctx_init(Ctx *c, const OrcScene *s)
+{
+    const float fx = (float)s->dims[0], fy = (float)s->dims[1], fz = (float)s->dims[2];
+    const float maxs = fmaxf(fmaxf(fx, fy), fz);
+    c->bbox = v3_make(fx / maxs, fy / maxs, fz / maxs);
+    c->tscale = v3_make(maxs / fx, maxs / fy, maxs / fz);
+    c->density_multiplier = s->cloud_size_m / s->mean_free_path_m;
+    c->sample_step = s->sample_step;
+    v3 l = v3_make(s->light_direction[0], s->light_direction[1], s->light_direction[2]);
+    l = v3_normalize(l);
+    l = v3_normalize(l);
+    c->light_dir = l;
+    c->light_rgb = v3_scale(v3_make(s->light_color[0], s->light_color[1], s->light_color[2]), s->light_intensity);
+    {
+        /* cloud.cuh:148-151, evaluated in float like the device code */
+        const float sunAngularRadiusDeg = 0.53f / 2;
+        const float sphereArea = 4 * ORC_PI_F;
+        const float sunArea = 2 * ORC_PI_F * (1 - cosf(sunAngularRadiusDeg * ORC_PI_F / 180.0f));
+        c->sun_ratio = sunArea / sphereArea;
+    }
+    c->density.texels = s->density;
+    c->density.nx = (int32_t)s->dims[0];
+    c->density.ny = (int32_t)s->dims[1];
+    c->density.nz = (int32_t)s->dims[2];
+    c->density.sx = c->tscale.x * fx;
+    c->density.sy = c->tscale.y * fy;
+    c->density.sz = c->tscale.z * fz;
+    c->inscatter = c->density;
+    c->inscatter.texels = s->inscatter;
+    c->mie = s->mie_tex;
+    c->chopped = s->chopped_mie_tex;
+    c->cdf = s->chopped_cdf_tex;
+    c->mie_n = s->mie_count;
+    c->max_depth = s->max_depth;
+    c->mode = s->mode;
+}
+
+/* Exposes the derived uniforms so tests can compare them with the product's. */
+ORC_API void orc_derived_uniforms(const OrcScene *s, float out[16])
+{
+    Ctx c;
+    ctx_init(&c, s);
+    out[0] = c.bbox.x; out[1] = c.bbox.y; out[2] = c.bbox.z;
+    out[3] = c.tscale.x; out[4] = c.tscale.y; out[5] = c.tscale.z;
+    out[6] = c.density_multiplier;
+    out[7] = c.light_dir.x; out[8] = c.light_dir.y; out[9] = c.light_dir.z;
+    out[10] = c.light_rgb.x; out[11] = c.light_rgb.y; out[12] = c.light_rgb.z;
+    out[13] = c.sun_ratio;
+    out[14] = c.density.sx; out[15] = c.sample_step;
+}
+
+/* isInBox, cloud.cuh:40-44 (0.01 slack on every side). */
+static inline int in_box(const Ctx *c, v3 p)
+{
+    return p.x >= -0.01f && p.y >= -0.01f && p.z >= -0.01f &&
+           p.x <= c->bbox.x + 0.01f && p.y <= c->bbox.y + 0.01f && p.z <= c->bbox.z + 0.01f;
+}
+
+/* sampleCloud cloud.cuh:58-62 / sampleInScatter :64-68 */
+static inline float sample_cloud(const Ctx *c, v3 pos, OrcCounters *k)
+{
+    k->density_lookups++;
+    return tex3_fetch(&c->density, pos);
+}
+static inline float sample_inscatter(const Ctx *c, v3 pos, OrcCounters *k)
+{
+    k->inscatter_lookups++;
+    return tex3_fetch(&c->inscatter, pos);
+}
+
+typedef struct { int scattered; v3 pos; float transmittance; } Event;
+
+/* getNextScatteringEvent, cloud.cuh:77-114 with stopAtScatterPos = true (shouldSampleSky is
+ * false, cloudRadianceMaterials.cu:25,36): step, THEN sample; collide when xi > T (strict). */
+static Event next_scattering_event(const Ctx *c, float optical_distance, v3 pos, v3 direction, OrcCounters *k)
+{
+    const v3 step_along_ray = v3_scale(direction, c->sample_step);
+    float transmittance = 1;
+    int scattered = 0;
+    v3 scatter_pos = v3_make(0, 0, 0);
+    while (in_box(c, pos)) {
+        pos = v3_add(pos, step_along_ray);
+        const float density = sample_cloud(c, pos, k) * c->density_multiplier;
+        const float extinction = density * c->sample_step;
+        const float current_transmit = ct_expf(-extinction);
+        transmittance *= current_transmit;
+        if (optical_distance > transmittance) {
+            scattered = 1;
+            /* pos - direction * log(xi / T) / density  (cloud.cuh:99) */
+            const float lg = ct_logf(optical_distance / transmittance);
+            scatter_pos = v3_sub(pos, v3_div(v3_scale(direction, lg), density));
+            break;
+        }
+    }
+    if (!scattered && !in_box(c, pos)) {
+        scatter_pos = pos;
+    }
+    Event e = { scattered, scatter_pos, transmittance };
+    return e;
+}
+
+/* getInScattering, cloud.cuh:146-158 (NEE through the pre-integrated shadow volume). */
+static v3 in_scattering(const Ctx *c, v3 scatter_pos, v3 direction, int chopped, OrcCounters *k)
+{
+    const float cos_light = v3_dot(v3_neg(c->light_dir), direction);
+    const float phase = orc_tex1d(chopped ? c->chopped : c->mie, c->mie_n, (cos_light + 1) / 2);
+    const float ins = sample_inscatter(c, scatter_pos, k);
+    v3 l = v3_scale(c->light_rgb, ins);
+    l = v3_scale(l, phase);
+    l = v3_scale(l, c->sun_ratio);
+    k->scatter_events++;
+    return l;
+}
+
+/* optix::Onb(n).inverse_transform(p) -- OptiX SDK 5.1 optixu_math_namespace.h (restated). */
+static v3 onb_inverse_transform(v3 n, v3 p)
+{
+    v3 b;
+    if (fabsf(n.x) > fabsf(n.z)) {
+        b = v3_make(-n.y, n.x, 0);
+    } else {
+        b = v3_make(0, -n.z, n.y);
+    }
+    b = v3_normalize(b);
+    const v3 t = v3_cross(b, n);
+    return v3_add(v3_add(v3_scale(t, p.x), v3_scale(b, p.y)), v3_scale(n, p.z));
+}
+
+/* getNewDirection, cloud.cuh:160-188: 16-step bisection on the chopped-Mie CDF texture, then
+ * uniformOnSphereCircle (random.cuh:122-131), rotate into the previous direction's frame. */
+static v3 new_direction(const Ctx *c, uint32_t *seed, v3 previous)
+{
+    float l = 0.f, r = 1.f, m;
+    const float val = orc_rnd(seed);
+    for (int i = 0; i < 16; i++) {
+        m = (l + r) / 2.f;
+        if (val > orc_tex1d(c->cdf, c->mie_n, m)) {
+            l = m;
+        } else {
+            r = m;
+        }
+    }
+    const float cos_theta = (l + r) - 1;
+    const float phi = orc_rnd(seed) * ORC_PI_F * 2;
+    const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+    float sn, cs;
+    ct_sincosf(phi, &sn, &cs);
+    const v3 local = v3_make(sin_theta * cs, sin_theta * sn, cos_theta);
+    return v3_normalize(onb_inverse_transform(previous, local));
+}
+
+/* intersect, cloudBBox.cu:7-37 with minimalRayDistance = 1e-6 (CloudMaterial.cpp:23), ray
+ * interval (sceneEPS = 0 [never set], RT_DEFAULT_MAX = 1e27).  Returns 1 and *t_hit on a hit. */
+static int intersect_box(const Ctx *c, v3 origin, v3 dir, float *t_hit)
+{
+    const v3 boxmin = v3_make(-c->bbox.x / 2, -c->bbox.y / 2, -c->bbox.z / 2);
+    const v3 boxmax = v3_make(c->bbox.x / 2, c->bbox.y / 2, c->bbox.z / 2);
+    const v3 t0 = v3_make((boxmin.x - origin.x) / dir.x, (boxmin.y - origin.y) / dir.y, (boxmin.z - origin.z) / dir.z);
+    const v3 t1 = v3_make((boxmax.x - origin.x) / dir.x, (boxmax.y - origin.y) / dir.y, (boxmax.z - origin.z) / dir.z);
+    const float tmin = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+    const float tmax = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+    const float ray_tmin = 0.0f, ray_tmax = 1e27f;
+    if (tmin <= tmax) {
+        if (tmin > ray_tmin && tmin < ray_tmax) {
+            *t_hit = tmin;
+            return 1;
+        }
+        const float minimal = 0.000001f;
+        if (minimal > ray_tmin && minimal < ray_tmax) {
+            *t_hit = minimal;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* Closest-hit programs of cloudRadianceMaterials.cu for one primary ray. */
+static v3 radiance_of_ray(const Ctx *c, v3 origin, v3 ray_dir, uint32_t seed, OrcCounters *k)
+{
+    v3 radiance = v3_make(0, 0, 0);
+    float t_hit;
+    k->paths++;
+    if (!intersect_box(c, origin, ray_dir, &t_hit)) {
+        return radiance; /* progressive.cu:44-46: empty miss program */
+    }
+    k->box_hits++;
+    v3 pos = v3_add(origin, v3_scale(ray_dir, t_hit));   /* :11 */
+    pos = v3_add(pos, v3_scale(c->bbox, 0.5f));            /* :12 */
+    v3 direction = v3_normalize(ray_dir);                  /* :17 */
+
+    if (c->mode == 2) {
+        /* singleScatterSunRadiance, :120-148 */
+        const Event e = next_scattering_event(c, orc_rnd(&seed), pos, direction, k);
+        if (e.scattered && in_box(c, e.pos)) {
+            radiance = v3_add(radiance, in_scattering(c, e.pos, direction, 0, k));
+        }
+        return radiance;
+    }
+    if (c->mode == 1) {
+        direction = new_direction(c, &seed, direction);    /* :86 */
+    }
+    uint32_t depth = 0;
+    while (in_box(c, pos)) {
+        depth++;
+        if (depth == c->max_depth) {
+            k->depth_capped++;
+            break;
+        }
+        const Event e = next_scattering_event(c, orc_rnd(&seed), pos, direction, k);
+        if (!e.scattered || !in_box(c, e.pos)) {
+            break;
+        }
+        /* totalRadiance :56 un-chopped Mie at depth 1; multipleScatter :105 always chopped */
+        const int chopped = (c->mode == 1) ? 1 : (depth != 1);
+        radiance = v3_add(radiance, in_scattering(c, e.pos, direction, chopped, k));
+        pos = e.pos;
+        direction = new_direction(c, &seed, direction);
+    }
+    return radiance;
+}
+
+/* pinholeCamera pathTracingCamera.cu:12-21 + trace<> cameraCommon.cuh:18-30 for the pixel
+ * window [x0,x1) x [y0,y1); frame_rgba is the full W x H float4 image (row 0 = bottom).
+ * Seed: tea<4>(x*4096 + y, subframe_id)  (cloudRadianceMaterials.cu:21 + deviation above). */
+ORC_API void orc_render_subframe(const OrcScene *s, uint32_t subframe_id,
+                                 uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                                 float *frame_rgba, OrcCounters *counters, int32_t threads)
+{
+    Ctx c;
+    ctx_init(&c, s);
+    const v3 eye = v3_make(s->eye[0], s->eye[1], s->eye[2]);
+    const v3 U = v3_make(s->U[0], s->U[1], s->U[2]);
+    const v3 V = v3_make(s->V[0], s->V[1], s->V[2]);
+    const v3 W = v3_make(s->W[0], s->W[1], s->W[2]);
+    uint64_t paths = 0, hits = 0, dl = 0, il = 0, se = 0, dc = 0;
+    const int64_t w = (int64_t)x1 - (int64_t)x0, h = (int64_t)y1 - (int64_t)y0;
+    const int64_t total = (w > 0 && h > 0) ? w * h : 0;
+#ifdef _OPENMP
+    if (threads <= 0) {
+        threads = omp_get_max_threads();
+    }
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : paths, hits, dl, il, se, dc)
+    for (int64_t idx = 0; idx < total; idx++) {
+        const uint32_t px = x0 + (uint32_t)(idx % w);
+        const uint32_t py = y0 + (uint32_t)(idx / w);
+        OrcCounters k = { 0, 0, 0, 0, 0, 0 };
+        /* d = pixel / size * 2 - 1  (cameraCommon.cuh:22) */
+        const float dx = (float)px / (float)s->width * 2.f - 1.f;
+        const float dy = (float)py / (float)s->height * 2.f - 1.f;
+        const v3 direction = v3_normalize(v3_add(v3_add(v3_scale(U, dx), v3_scale(V, dy)), W));
+        const uint32_t seed = orc_tea4(px * 4096u + py, subframe_id);
+        const v3 rad = radiance_of_ray(&c, eye, direction, seed, &k);
+        float *out = frame_rgba + 4 * ((size_t)py * s->width + px);
+        out[0] = rad.x; out[1] = rad.y; out[2] = rad.z; out[3] = 1.0f;
+        paths += k.paths; hits += k.box_hits; dl += k.density_lookups;
+        il += k.inscatter_lookups; se += k.scatter_events; dc += k.depth_capped;
+    }
+    if (counters) {
+        counters->paths += paths; counters->box_hits += hits; counters->density_lookups += dl;
+        counters->inscatter_lookups += il; counters->scatter_events += se; counters->depth_capped += dc;
+    }
+}
+
+/* The same estimator started from an arbitrary (origin, direction) -- estimateEmission,
+ * pointEmissionCamera.cu:20-40: launchID is 1-D so the seed is tea<4>(id*4096 + 0, frame). */
+ORC_API void orc_point_radiance(const OrcScene *s, uint32_t launch_id, uint32_t subframe_id,
+                                const float origin[3], const float direction[3], float rgb_out[3],
+                                OrcCounters *counters)
+{
+    Ctx c;
+    ctx_init(&c, s);
+    OrcCounters k = { 0, 0, 0, 0, 0, 0 };
+    const uint32_t seed = orc_tea4(launch_id * 4096u, subframe_id);
+    const v3 rad = radiance_of_ray(&c, v3_make(origin[0], origin[1], origin[2]),
+                                   v3_make(direction[0], direction[1], direction[2]), seed, &k);
+    rgb_out[0] = rad.x; rgb_out[1] = rad.y; rgb_out[2] = rad.z;
+    if (counters) {
+        counters->paths += k.paths; counters->box_hits += k.box_hits;
+        counters->density_lookups += k.density_lookups; counters->inscatter_lookups += k.inscatter_lookups;
+        counters->scatter_events += k.scatter_events; counters->depth_capped += k.depth_capped;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Shadow volume: inScatter, src/CUDA/inScatter.cu:40-66 (host side VDBCloud.cpp:57-86).
+ * Sample THEN step; marches 1/sampleStep steps toward -lightDirection; early out when
+ * T*255 < 1; stores uchar(T*255) truncating.  `s->inscatter` is ignored.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_inscatter(const OrcScene *s, uint8_t *out, int32_t threads)
+{
+    Ctx c;
+    ctx_init(&c, s);
+    const int32_t nx = c.density.nx, ny = c.density.ny, nz = c.density.nz;
+    const int32_t maxn = nx > ny ? (nx > nz ? nx : nz) : (ny > nz ? ny : nz);
+    const float max_size = (float)maxn;
+    const float min_scale = fminf(fminf(c.tscale.x, c.tscale.y), c.tscale.z);
+    const v3 step_to_light = v3_scale(v3_neg(v3_normalize(c.light_dir)), c.sample_step);
+    const int step_count = (int)(1 / c.sample_step);
+#ifdef _OPENMP
+    if (threads <= 0) {
+        threads = omp_get_max_threads();
+    }
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int32_t z = 0; z < nz; z++) {
+        OrcCounters k = { 0, 0, 0, 0, 0, 0 };
+        for (int32_t y = 0; y < ny; y++) {
+            for (int32_t x = 0; x < nx; x++) {
+                v3 p = v3_make((float)x / max_size, (float)y / max_size, (float)z / max_size);
+                p = v3_div(p, min_scale);
+                float transmittance = 1;
+                for (int i = 0; i < step_count; i++) {
+                    const float density = sample_cloud(&c, p, &k) * c.density_multiplier;
+                    const float extinction = density * c.sample_step;
+                    transmittance *= ct_expf(-extinction);
+                    p = v3_add(p, step_to_light);
+                    if (transmittance * 255.f < 1.f) {
+                        break;
+                    }
+                }
+                out[((size_t)z * ny + y) * nx + x] = (uint8_t)(transmittance * 255.f);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Camera frame: sutil::calculateCameraVariables, src/Util/sutil.cpp:501-524, called with
+ * fov_is_vertical = false by Camera::updatePosition (Camera.cpp:100-134).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_camera_variables(const float eye[3], const float lookat[3], const float up[3],
+                                  float fov, float aspect_ratio, float U[3], float V[3], float W[3])
+{
+    const v3 e = v3_make(eye[0], eye[1], eye[2]);
+    const v3 w = v3_sub(v3_make(lookat[0], lookat[1], lookat[2]), e);
+    const float wlen = sqrtf(v3_dot(w, w));
+    v3 u = v3_normalize(v3_cross(w, v3_make(up[0], up[1], up[2])));
+    v3 v = v3_normalize(v3_cross(u, w));
+    const float ulen = wlen * tanf(0.5f * fov * ORC_PI_F / 180.0f);
+    u = v3_scale(u, ulen);
+    const float vlen = ulen / aspect_ratio;
+    v = v3_scale(v, vlen);
+    U[0] = u.x; U[1] = u.y; U[2] = u.z;
+    V[0] = v.x; V[1] = v.y; V[2] = v.z;
+    W[0] = w.x; W[1] = w.y; W[2] = w.z;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Volume quantiser + mip pyramid: Resources::loadVolumeBuffer Resources.cpp:92-141 and
+ * generateMipmaps :169-209.  `grid` is the dense payload (active bbox), x fastest.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_quantize_volume(const float *grid, const uint32_t pd[3], uint8_t *tex)
+{
+    const size_t n = (size_t)pd[0] * pd[1] * pd[2];
+    double max_density = grid[0];
+    for (size_t i = 1; i < n; i++) {
+        if (grid[i] > max_density) {
+            max_density = grid[i];
+        }
+    }
+    const uint32_t tx = pd[0] + 2, ty = pd[1] + 2, tz = pd[2] + 2;
+    memset(tex, 0, (size_t)tx * ty * tz);
+    for (uint32_t z = 0; z < pd[2]; z++) {
+        for (uint32_t y = 0; y < pd[1]; y++) {
+            for (uint32_t x = 0; x < pd[0]; x++) {
+                const float v = grid[((size_t)z * pd[1] + y) * pd[0] + x];
+                tex[((size_t)(z + 1) * ty + (y + 1)) * tx + (x + 1)] = (uint8_t)(v / max_density * 255);
+            }
+        }
+    }
+}
+
+static inline uint32_t mip_dim(uint32_t d, uint32_t level)
+{
+    const uint32_t v = d >> level;
+    return v ? v : 1;
+}
+
+ORC_API uint32_t orc_mip_levels(const uint32_t dims[3])
+{
+    uint32_t m = dims[0] > dims[1] ? dims[0] : dims[1];
+    m = m > dims[2] ? m : dims[2];
+    uint32_t levels = 1;
+    while (m /= 2) {
+        levels++;
+    }
+    return levels;
+}
+
+/* out must hold sum over levels of the level sizes; returns total bytes written. */
+ORC_API size_t orc_generate_mipmaps(const uint8_t *level0, const uint32_t dims[3], uint8_t *out)
+{
+    const uint32_t levels = orc_mip_levels(dims);
+    size_t off = 0;
+    uint32_t px = dims[0], py = dims[1], pz = dims[2];
+    memcpy(out, level0, (size_t)px * py * pz);
+    const uint8_t *prev = out;
+    off += (size_t)px * py * pz;
+    for (uint32_t level = 1; level < levels; level++) {
+        const uint32_t cx = mip_dim(dims[0], level), cy = mip_dim(dims[1], level), cz = mip_dim(dims[2], level);
+        uint8_t *cur = out + off;
+        for (uint32_t z = 0; z < cz; z++) {
+            for (uint32_t y = 0; y < cy; y++) {
+                for (uint32_t x = 0; x < cx; x++) {
+                    uint16_t acc = 0;
+                    for (uint32_t d = 0; d < 8; d++) {
+                        const uint32_t sx = x * 2 + (d & 1), sy = y * 2 + ((d >> 1) & 1), sz = z * 2 + (d >> 2);
+                        if (sx < px && sy < py && sz < pz) { /* TextureView3D::get returns 0 out of range */
+                            acc = (uint16_t)(acc + prev[((size_t)sz * py + sy) * px + sx]);
+                        }
+                    }
+                    cur[((size_t)z * cy + y) * cx + x] = (uint8_t)(acc / 8);
+                }
+            }
+        }
+        prev = cur;
+        off += (size_t)cx * cy * cz;
+        px = cx; py = cy; pz = cz;
+    }
+    return off;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Progressive accumulation: updateFrameResult, src/CUDA/progressive.cu:17-27 (n = 1-based
+ * subframeId, all four channels).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_accumulate(const float *frame, float *mean, float *m2, uint32_t subframe_id, size_t pixels)
+{
+    const float new_weight = 1.0f / (float)subframe_id;
+    for (size_t i = 0; i < pixels * 4; i++) {
+        const float nr = frame[i];
+        const float pm = mean[i];
+        const float nm = pm + (nr - pm) * new_weight;
+        mean[i] = nm;
+        m2[i] = m2[i] + (nr - pm) * (nr - nm);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Tonemap: reinhard.cu:20-84 (firstPass column sums in y order, secondPass serial sum over
+ * columns / totalPixels, applyReinhard).  clamp(f,0,1) = fmaxf(0, fminf(f,1)) maps the NaN of
+ * black pixels (0 * (0/0)) to 1.
+ * ------------------------------------------------------------------------------------------ */
+static inline float luminance4(const float *c)
+{
+    return c[0] * 0.265068f + c[1] * 0.67023428f + c[2] * 0.06409157f + c[3] * 0.0f;
+}
+
+ORC_API float orc_reinhard(const float *mean, uint32_t width, uint32_t height, float exposure, uint8_t *screen)
+{
+    const float DELTA = 0.00001f;
+    float *cols = (float *)malloc(sizeof(float) * width);
+    for (uint32_t x = 0; x < width; x++) {
+        float sum = 0;
+        for (uint32_t y = 0; y < height; y++) {
+            const float lum = luminance4(mean + 4 * ((size_t)y * width + x));
+            sum += lum + DELTA;
+        }
+        cols[x] = sum;
+    }
+    float result = 0;
+    for (uint32_t i = 0; i < width; i++) {
+        result += cols[i];
+    }
+    free(cols);
+    const uint32_t total_pixels = width * height;
+    result = result / (float)total_pixels;
+    const float avg = result;
+    const float inv_gamma = 1.f / 2.2f;
+    for (size_t i = 0; i < (size_t)width * height; i++) {
+        const float *color = mean + 4 * i;
+        const float lw = luminance4(color);
+        float ld = lw * exposure / avg;
+        ld = ld / (1.f + ld);
+        const float sc = ld / lw;
+        float rgb[3];
+        for (int ch = 0; ch < 3; ch++) {
+            float v = color[ch] * sc;
+            v = fmaxf(0.f, fminf(v, 1.f));
+            v = ct_powf(v, inv_gamma);
+            rgb[ch] = v * 255;
+        }
+        screen[4 * i + 0] = (uint8_t)rgb[0];
+        screen[4 * i + 1] = (uint8_t)rgb[1];
+        screen[4 * i + 2] = (uint8_t)rgb[2];
+        screen[4 * i + 3] = 255;
+    }
+    return avg;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Convergence: Camera::isConverged, src/Scene/Cameras/Camera.cpp:232-268 (channel x only).
+ * Returns 1 if converged; *unconverged gets the count of pixels outside the interval.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API int32_t orc_is_converged(const float *mean, const float *m2, uint32_t subframe_id, size_t pixels,
+                                 uint64_t *unconverged)
+{
+    if (subframe_id < 100) {
+        if (unconverged) {
+            *unconverged = pixels;
+        }
+        return 0;
+    }
+    size_t converged = 0;
+    for (size_t id = 0; id < pixels; id++) {
+        const float var = m2[4 * id];
+        const float N = (float)subframe_id;
+        const float sigma = sqrtf(var / N);
+        const float abs_ci = 1.96f * sigma / sqrtf(N);
+        const float rel_ci = abs_ci / (mean[4 * id] + 1.1920929e-07f /* FLT_EPSILON */);
+        if (rel_ci < 0.02f || abs_ci < 1e-2f) {
+            converged++;
+        }
+    }
+    if (unconverged) {
+        *unconverged = pixels - converged;
+    }
+    return (pixels - converged) < 500;
+}
+
+/* The literal 16-step bisection of getNewDirection (cloud.cuh:162-180) for `count` consecutive
+ * 24-bit randoms: k_out[i] = l * 65536 after the loop, i.e. cos(theta) = (2k+1)/65536 - 1.
+ * Used to check the product's guide-table inversion exhaustively. */
+ORC_API void orc_cdf_bisect_k(const float *cdf, uint32_t n, uint32_t first_u24, uint32_t count, uint32_t *k_out,
+                              int32_t threads)
+{
+#ifdef _OPENMP
+    if (threads <= 0) {
+        threads = omp_get_max_threads();
+    }
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)count; i++) {
+        const float val = (float)(first_u24 + (uint32_t)i) / (float)0x01000000;
+        float l = 0.f, r = 1.f, m;
+        for (int it = 0; it < 16; it++) {
+            m = (l + r) / 2.f;
+            if (val > orc_tex1d(cdf, n, m)) {
+                l = m;
+            } else {
+                r = m;
+            }
+        }
+        k_out[i] = (uint32_t)(l * 65536.0f);
+    }
+}
+
+/* Thin wrappers so tests can drive the deterministic math and texture units directly. */
+ORC_API float orc_expf(float x) { return ct_expf(x); }
+ORC_API float orc_logf(float x) { return ct_logf(x); }
+ORC_API float orc_powf(float x, float y) { return ct_powf(x, y); }
+ORC_API void orc_sincosf(float x, float *s, float *c) { ct_sincosf(x, s, c); }
+ORC_API float orc_tex3d(const uint8_t *texels, const uint32_t dims[3], const float pos_box[3])
+{
+    OrcScene s;
+    memset(&s, 0, sizeof s);
+    s.dims[0] = dims[0]; s.dims[1] = dims[1]; s.dims[2] = dims[2];
+    s.density = texels; s.inscatter = texels;
+    s.cloud_size_m = 1; s.mean_free_path_m = 1; s.sample_step = 1; s.light_direction[2] = 1;
+    Ctx c;
+    ctx_init(&c, &s);
+    return tex3_fetch(&c.density, v3_make(pos_box[0], pos_box[1], pos_box[2]));
+}
+ORC_API int32_t orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

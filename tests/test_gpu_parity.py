@@ -1,0 +1,282 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X): every result comes from the HIP
+kernels through the C ABI and is compared with the CPU oracle on the same seeded inputs.
+
+Tolerance: the north star allows 1e-3 relative L2; because the kernels and the oracle share the
+deterministic float32 contract of include/ct_fmath.h the comparison is BIT-EXACT here (radiance,
+mean, M2, shadow volume, screen bytes, work counters).
+"""
+import numpy as np
+import pytest
+
+import _oracle as O
+import deepestscatter_amd as ds
+from deepestscatter_amd import _lib
+from conftest import sphere_volume
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def make_pair(tex, w, h, mode=0, **kw):
+    tr = ds.CloudTracer(tex, width=w, height=h, mode=mode, **kw)
+    okw = {k: v for k, v in kw.items() if k in ("cloud_size_m", "mean_free_path_m", "sample_step", "max_depth",
+                                                 "light_direction", "light_color", "light_intensity")}
+    orc = O.Oracle(tex, w, h, mode=mode, fast=True, **okw)
+    return tr, orc
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_loaded_library_is_the_in_tree_hip_extension():
+    L = _lib.load()
+    assert str(_lib.LIB_PATH).endswith("deepestscatter_amd/libcloudtrace.so")
+    with open("/proc/self/maps") as f:
+        assert any("deepestscatter_amd/libcloudtrace.so" in line for line in f)
+    assert L.ct_tile_owner(1, 1, 4) == 0
+
+
+@pytest.mark.parametrize("dims", [(32, 32, 32), (20, 28, 36), (40, 24, 16)])
+def test_shadow_volume_bit_exact(dims):
+    tex = sphere_volume(dims=dims, seed=2)
+    tr, orc = make_pair(tex, 8, 8)
+    got = tr.inscatter()
+    assert got.shape == orc.inscatter.shape
+    assert np.array_equal(got, orc.inscatter)
+    assert np.array_equal(tr.download(_lib.CT_BUF_DENSITY), tex)
+    tr.close()
+
+
+def test_shadow_volume_other_light_and_step():
+    tex = sphere_volume(24, seed=4)
+    tr, orc = make_pair(tex, 8, 8, light_direction=(0.586, -0.766, -0.271), sample_step=1.0 / 128.0,
+                        cloud_size_m=3000.0)
+    assert np.array_equal(tr.inscatter(), orc.inscatter)
+    tr.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_subframe_radiance_bit_exact_all_modes(mode):
+    tex = sphere_volume(32, seed=1)
+    w, h = 32, 24
+    tr, orc = make_pair(tex, w, h, mode=mode)
+    for sid in (1, 2, 7):
+        tr.render_subframe(sid)
+        got = tr.frame()
+        ref = orc.render_subframe(sid)
+        assert np.array_equal(got, ref), (mode, sid, rel_l2(got, ref))
+    assert tr.counters() == orc.counters.as_dict()
+    assert np.isfinite(tr.frame()).all()
+    tr.close()
+
+
+def test_progressive_mean_and_m2_bit_exact():
+    tex = sphere_volume(32, seed=3)
+    w, h = 24, 24
+    tr, orc = make_pair(tex, w, h, mode=0)
+    mean, m2 = orc.render(16)
+    tr.render_accumulate(1, 5)      # two batches of different size
+    tr.render_accumulate(6, 11)
+    assert tr.subframes == 16
+    assert np.array_equal(tr.mean(), mean)
+    assert np.array_equal(tr.m2(), m2)
+    assert rel_l2(tr.mean(), mean) <= 1e-3       # the north-star bar, trivially
+    assert tr.counters() == orc.counters.as_dict()
+    # separate render + accumulate calls (the reference's two launches) give the same thing
+    tr.reset()
+    for sid in range(1, 5):
+        tr.render_subframe(sid)
+        tr.accumulate(sid)
+    mean4, m24 = O.Oracle(tex, w, h, mode=0, fast=True, inscatter=orc.inscatter).render(4)
+    assert np.array_equal(tr.mean(), mean4) and np.array_equal(tr.m2(), m24)
+    tr.close()
+
+
+def test_ragged_frame_and_noncubic_volume():
+    tex = sphere_volume(dims=(20, 28, 36), seed=5)
+    w, h = 37, 21                      # not multiples of the 8x8 tile
+    tr, orc = make_pair(tex, w, h, mode=0)
+    mean, m2 = orc.render(3)
+    tr.render_accumulate(1, 3)
+    assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2)
+    tr.close()
+
+
+def test_simple_kernel_equals_persistent_kernel():
+    tex = sphere_volume(32, seed=6)
+    a = ds.CloudTracer(tex, width=40, height=32, mode=0)
+    b = ds.CloudTracer(tex, width=40, height=32, mode=0, flags=_lib.CT_FLAG_SIMPLE_KERNEL)
+    a.render_accumulate(1, 4)
+    b.render_accumulate(1, 4)
+    assert np.array_equal(a.mean(), b.mean()) and np.array_equal(a.m2(), b.m2())
+    assert a.counters() == b.counters()
+    a.close()
+    b.close()
+
+
+def test_depth_cap_and_thick_medium():
+    tex = sphere_volume(24)
+    tr, orc = make_pair(tex, 16, 16, mode=0, max_depth=6, cloud_size_m=20000.0)
+    mean, _ = orc.render(2)
+    tr.render_accumulate(1, 2)
+    assert np.array_equal(tr.mean(), mean)
+    c = tr.counters()
+    assert c == orc.counters.as_dict() and c["depth_capped"] > 0
+    tr.close()
+
+
+def test_empty_volume_and_camera_inside_box():
+    tex = np.zeros((16, 16, 16), np.uint8)
+    tr, orc = make_pair(tex, 16, 16)
+    tr.render_accumulate(1, 2)
+    assert np.all(tr.mean()[..., :3] == 0) and np.all(tr.mean()[..., 3] == 1)
+    assert np.all(tr.inscatter() == 255)
+    tr.close()
+    # camera inside the cloud's box: intersect reports minimalRayDistance (cloudBBox.cu:29-35)
+    tex = sphere_volume(24, seed=8)
+    tr, orc = make_pair(tex, 16, 16)
+    eye = (0.1, 0.05, -0.2)
+    U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 60.0, 1.0)
+    tr.set_camera(eye, U, V, W)
+    orc.set_camera(eye, U, V, W)
+    tr.render_subframe(3)
+    assert np.array_equal(tr.frame(), orc.render_subframe(3))
+    tr.close()
+
+
+def test_coloured_light_and_intensity_linearity():
+    tex = sphere_volume(24, seed=9)
+    tr, orc = make_pair(tex, 16, 16, light_color=(1.0, 0.5, 0.25), light_intensity=3e5)
+    tr.render_subframe(1)
+    f = tr.frame()
+    assert np.array_equal(f, orc.render_subframe(1))
+    assert not np.array_equal(f[..., 0], f[..., 1])
+    # doubling the intensity doubles every sample exactly (power of two, no rounding)
+    tr2 = ds.CloudTracer(tex, width=16, height=16, light_color=(1.0, 0.5, 0.25), light_intensity=6e5)
+    tr2.render_subframe(1)
+    assert np.array_equal(tr2.frame()[..., :3], f[..., :3] * 2)
+    tr.close()
+    tr2.close()
+
+
+@pytest.mark.parametrize("count", [2, 3])
+def test_pixel_tile_shards_sum_to_the_whole(count):
+    tex = sphere_volume(32, seed=10)
+    w, h = 40, 24
+    whole = ds.CloudTracer(tex, width=w, height=h)
+    whole.render_accumulate(1, 3)
+    total_mean = np.zeros((h, w, 4), np.float32)
+    total_m2 = np.zeros_like(total_mean)
+    ctr = None
+    for i in range(count):
+        sh = ds.CloudTracer(tex, width=w, height=h, shard_index=i, shard_count=count)
+        sh.render_accumulate(1, 3)
+        m = sh.mean()
+        mask = ds.shard_mask(w, h, i, count)
+        assert np.all(m[~mask] == 0)                     # foreign pixels untouched: sum == merge
+        total_mean += m
+        total_m2 += sh.m2()
+        c = sh.counters()
+        ctr = c if ctr is None else {k: ctr[k] + c[k] for k in c}
+        sh.close()
+    assert np.array_equal(total_mean, whole.mean())
+    assert np.array_equal(total_m2, whole.m2())
+    assert ctr == whole.counters()
+    whole.close()
+
+
+def test_tonemap_and_convergence_bit_exact():
+    tex = sphere_volume(32, seed=12)
+    w, h = 32, 32
+    tr, orc = make_pair(tex, w, h)
+    mean, m2 = orc.render(8)
+    tr.render_accumulate(1, 8)
+    screen, avg = tr.tonemap(0.4)
+    ref_screen, ref_avg = O.reinhard(mean, 0.4)
+    assert avg == ref_avg
+    assert np.array_equal(screen, ref_screen)
+    assert np.array_equal(tr.download(_lib.CT_BUF_SCREEN), ref_screen)
+    assert tr.is_converged() == (False, w * h)          # < 100 subframes (Camera.cpp:234)
+    tr.set_subframes(100)                                 # same buffers, pretend N = 100
+    assert tr.is_converged() == O.is_converged(mean, m2, 100)
+    tr.close()
+
+
+def test_cdf_inversion_exhaustive():
+    """All 2^24 values of the random number give the same cos(theta) as the literal 16-step
+    bisection of cloud.cuh:162-180."""
+    tr = ds.CloudTracer(sphere_volume(16), width=8, height=8)
+    ref = O.cdf_bisect_k(0, 1 << 24)
+    got = tr.debug_cdf_inversion(0, 1 << 24)
+    assert np.array_equal(got, ref)
+    tr.close()
+
+
+def test_error_behaviour_on_device():
+    tex = sphere_volume(16)
+    tr = ds.CloudTracer(tex, width=16, height=16)
+    with pytest.raises(_lib.CloudTraceError) as e:
+        tr.render_accumulate(5, 1)                      # out of order
+    assert e.value.code == _lib.CT_E_STATE
+    with pytest.raises(_lib.CloudTraceError) as e:
+        tr.accumulate(0)
+    assert e.value.code == _lib.CT_E_INVAL
+    with pytest.raises(_lib.CloudTraceError):
+        tr.download(99)
+    tr.render_accumulate(1, 1)                           # still usable after errors
+    tr.reset()
+    assert tr.subframes == 0 and tr.counters()["paths"] == 0
+    tr.close()
+
+
+def test_golden_fixture_on_gpu():
+    from test_golden import load_golden
+    g = load_golden()
+    for case in g["cases"]:
+        tex = g["volumes"][case["volume"]]
+        tr = ds.CloudTracer(tex, width=case["width"], height=case["height"], mode=case["mode"])
+        tr.render_accumulate(1, case["spp"])
+        assert np.array_equal(tr.mean(), case["mean"]), case["name"]
+        assert np.array_equal(tr.m2(), case["m2"]), case["name"]
+        c = tr.counters()
+        assert [c[k] for k in ("paths", "box_hits", "density_lookups", "inscatter_lookups", "scatter_events",
+                               "depth_capped")] == list(case["counters"]), case["name"]
+        assert np.array_equal(tr.inscatter(), g["inscatter"][case["volume"]])
+        tr.close()
+
+
+# ---- full-size properties (BASELINE.json config 2: 512^3 volume, 1024^2 frame) -------------------------
+def test_full_size_properties_512_1024():
+    n = 512
+    tex = ds.make_procedural_cloud(n)
+    w = h = 1024
+    tr = ds.CloudTracer(tex, width=w, height=h)
+    tr.render_accumulate(1, 2)
+    m = tr.mean()
+    c = tr.counters()
+    assert np.isfinite(m).all() and np.all(m[..., :3] >= 0) and np.all(m[..., 3] == 1)
+    assert c["paths"] == 2 * w * h and c["box_hits"] <= c["paths"]
+    assert c["scatter_events"] == c["inscatter_lookups"] <= c["density_lookups"]
+    # determinism: the schedule (persistent waves, atomics on the queue) never changes a pixel
+    tr.reset()
+    tr.render_accumulate(1, 2)
+    assert np.array_equal(tr.mean(), m) and tr.counters() == c
+    # oracle on a window of the same job (the full frame would take the CPU minutes)
+    ins = tr.inscatter()
+    orc = O.Oracle(tex, w, h, fast=True, inscatter=ins)
+    win = (480, 500, 544, 532)
+    ref, _ = orc.render(2, window=win)
+    x0, y0, x1, y1 = win
+    assert np.array_equal(m[y0:y1, x0:x1], ref[y0:y1, x0:x1])
+    # shards tile the frame: two half-jobs merge into the whole
+    merged = np.zeros_like(m)
+    for i in range(2):
+        sh = ds.CloudTracer(tex, width=w, height=h, shard_index=i, shard_count=2)
+        sh.render_accumulate(1, 2)
+        merged += sh.mean()
+        sh.close()
+    assert np.array_equal(merged, m)
+    tr.close()

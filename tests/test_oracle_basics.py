@@ -1,0 +1,300 @@
+"""CPU tests of the oracle against closed forms and independent restatements (no GPU).
+
+The reference has no tests or golden vectors, so the oracle is pinned by:
+known answers that follow from the reference's formulas, independent numpy restatements written
+from the same reference lines, and the goldens of SURVEY.md section 8(c).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from conftest import sphere_volume
+
+
+# ---- RNG (random.cuh:34-70) -------------------------------------------------------------------
+def tea4_py(v0, v1):
+    M = 0xFFFFFFFF
+    s0 = 0
+    for _ in range(4):
+        s0 = (s0 + 0x9E3779B9) & M
+        v0 = (v0 + ((((v1 << 4) & M) + 0xA341316C) & M ^ ((v1 + s0) & M) ^ (((v1 >> 5) + 0xC8013EA4) & M))) & M
+        v1 = (v1 + ((((v0 << 4) & M) + 0xAD90777D) & M ^ ((v0 + s0) & M) ^ (((v0 >> 5) + 0x7E95761E) & M))) & M
+    return v0
+
+
+def test_tea4_matches_independent_python(oracle_lib):
+    rng = np.random.default_rng(1)
+    for v0, v1 in [(0, 0), (1, 2), (4096 * 7 + 3, 1), (0xFFFFFFFF, 0xFFFFFFFF)] + \
+            [tuple(int(x) for x in rng.integers(0, 2**32, 2)) for _ in range(200)]:
+        assert oracle_lib.orc_tea4(v0, v1) == tea4_py(v0, v1)
+
+
+def test_tea4_golden(oracle_lib):
+    # committed known answers (tests/golden/rng.npz is produced by tools/make_golden.py)
+    assert oracle_lib.orc_tea4(1, 2) == 0x7F75A0A1
+
+
+def test_lcg_rnd_sequence(oracle_lib):
+    s = C.c_uint32(12345)
+    state = 12345
+    for _ in range(100):
+        state = (1664525 * state + 1013904223) & 0xFFFFFFFF
+        r = oracle_lib.orc_rnd(C.byref(s))
+        assert s.value == state
+        assert r == np.float32(state & 0xFFFFFF) / np.float32(16777216.0)
+        assert 0.0 <= r < 1.0
+
+
+# ---- Mie tables (Mie.cpp) -------------------------------------------------------------------------
+def test_mie_raw_spot_values():
+    mie, chopped = O.load_mie_raw()
+    # SURVEY.md section 8(c)(ii)
+    assert mie[0] == np.float32(0.7136052853)
+    assert mie[4095] == np.float32(19086.0499712)
+    assert chopped[4095] == np.float32(9.9666332937)
+    assert list(np.nonzero(mie != chopped)[0]) == list(range(4081, 4096))
+    assert abs(float(mie.astype(np.float64).sum()) - 21540.0213) < 0.01
+    assert abs(float(chopped.astype(np.float64).sum()) - 2158.0787) < 0.01
+
+
+def test_mie_textures_normalisation():
+    mie_t, chopped_t, cdf = O.mie_textures()
+    assert abs(float(mie_t.astype(np.float64).mean()) - 1.0) < 1e-4       # phase / mean(phase)
+    assert abs(float(chopped_t.astype(np.float64).mean()) - 1.0) < 1e-4
+    assert np.all(np.diff(cdf) > 0)                                       # strictly increasing
+    assert abs(float(cdf[-1]) - 1.0) < 1e-3
+    # float32 running sums in index order (Mie.cpp:8215-8226, 8254-8265)
+    raw = O.load_mie_raw()[1]
+    s = np.float32(0)
+    for v in raw:
+        s = np.float32(s + v)
+    acc = np.float32(0)
+    for i in (0, 1, 2, 100, 4095):
+        pass
+    acc = np.float32(0)
+    ref = np.empty(4096, np.float32)
+    for i, v in enumerate(raw):
+        acc = np.float32(acc + np.float32(v / s))
+        ref[i] = acc
+    assert np.array_equal(ref, cdf)
+
+
+# ---- deterministic math (include/ct_fmath.h) -------------------------------------------------------
+def _ulp_err(got, ref):
+    ref32 = ref.astype(np.float32)
+    ulp = np.abs(np.spacing(ref32)).astype(np.float64)
+    return float(np.max(np.abs(got.astype(np.float64) - ref) / ulp))
+
+
+def test_fmath_accuracy(oracle_lib):
+    L = oracle_lib
+    xs = np.linspace(-30, 3, 30001).astype(np.float32)
+    got = np.array([L.orc_expf(float(x)) for x in xs], np.float32)
+    assert _ulp_err(got, np.exp(xs.astype(np.float64))) <= 2.0
+    xs = np.exp(np.linspace(-40, 40, 30001)).astype(np.float32)
+    got = np.array([L.orc_logf(float(x)) for x in xs], np.float32)
+    assert _ulp_err(got, np.log(xs.astype(np.float64))) <= 2.0
+    xs = np.linspace(0, 2 * np.pi, 30001).astype(np.float32)
+    s, c = C.c_float(), C.c_float()
+    gs, gc = [], []
+    for x in xs:
+        L.orc_sincosf(float(x), C.byref(s), C.byref(c))
+        gs.append(s.value)
+        gc.append(c.value)
+    assert np.max(np.abs(np.array(gs) - np.sin(xs.astype(np.float64)))) < 2e-7
+    assert np.max(np.abs(np.array(gc) - np.cos(xs.astype(np.float64)))) < 2e-7
+    # edge cases
+    assert L.orc_expf(0.0) == 1.0
+    assert L.orc_expf(-200.0) == 0.0
+    assert L.orc_logf(1.0) == 0.0
+    assert L.orc_powf(0.0, 0.4545) == 0.0
+    assert L.orc_powf(1.0, 0.4545) == 1.0
+    xs = np.linspace(1e-4, 1, 2001).astype(np.float32)
+    got = np.array([L.orc_powf(float(x), 1 / 2.2) for x in xs])
+    assert np.max(np.abs(got / xs.astype(np.float64) ** (1 / 2.2) - 1)) < 2e-6
+
+
+# ---- texture units ---------------------------------------------------------------------------------
+def tex3d_numpy(t, p):
+    """Independent restatement: CUDA linear filtering, clamp, normalised coords, /255."""
+    nz, ny, nx = t.shape
+    m = max(nx, ny, nz)
+    out = []
+    for (px, py, pz) in p:
+        c = [px * m - 0.5, py * m - 0.5, pz * m - 0.5]   # textureScale * N = maxDim for every axis
+        i = [int(np.floor(v)) for v in c]
+        f = [v - iv for v, iv in zip(c, i)]
+        acc = 0.0
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    xi = min(max(i[0] + dx, 0), nx - 1)
+                    yi = min(max(i[1] + dy, 0), ny - 1)
+                    zi = min(max(i[2] + dz, 0), nz - 1)
+                    w = (f[0] if dx else 1 - f[0]) * (f[1] if dy else 1 - f[1]) * (f[2] if dz else 1 - f[2])
+                    acc += w * float(t[zi, yi, xi])
+        out.append(acc / 255.0)
+    return np.array(out)
+
+
+def test_tex3d_matches_numpy_trilinear():
+    rng = np.random.default_rng(3)
+    t = rng.integers(0, 256, (9, 12, 17), dtype=np.uint8)
+    m = 17.0
+    pts = rng.random((300, 3)) * np.array([17 / m, 12 / m, 9 / m]) * 1.1 - 0.03   # incl. outside the box
+    got = np.array([O.tex3d(t, p) for p in pts.astype(np.float32)])
+    ref = tex3d_numpy(t, pts.astype(np.float32).astype(np.float64))
+    assert np.max(np.abs(got - ref)) < 2e-6
+    # texel centres return the texel exactly
+    for (x, y, z) in [(0, 0, 0), (16, 11, 8), (5, 7, 3)]:
+        p = np.array([(x + 0.5) / m, (y + 0.5) / m, (z + 0.5) / m], np.float32)
+        assert abs(O.tex3d(t, p) - t[z, y, x] / 255.0) < 1e-6
+
+
+def test_tex1d_centres_and_clamp(oracle_lib):
+    tab = np.arange(4096, dtype=np.float32) * 0.5
+    f = lambda u: oracle_lib.orc_tex1d(tab.ctypes.data_as(C.c_void_p), 4096, float(u))
+    assert f((100 + 0.5) / 4096) == tab[100]
+    assert f(0.0) == tab[0] and f(-0.3) == tab[0]
+    assert f(1.0) == tab[4095] and f(1.7) == tab[4095]
+    assert abs(f((100 + 1.0) / 4096) - 0.5 * (tab[100] + tab[101])) < 1e-4
+
+
+# ---- camera (sutil.cpp:501-524; Camera.cpp:37-39,102-109) --------------------------------------------
+def test_camera_default_pose_goldens():
+    U, V, W = O.camera_variables(aspect=2.0)
+    assert np.allclose(W, [-2.5, 0.4, 0.0])
+    assert abs(np.linalg.norm(W) - 2.5318) < 1e-4
+    assert abs(np.linalg.norm(U) - 0.6784) < 1e-4
+    assert abs(np.linalg.norm(V) - 0.6784 / 2.0) < 1e-4          # fov is horizontal
+    assert abs(np.dot(U, V)) < 1e-6 and abs(np.dot(U, W)) < 1e-6 and abs(np.dot(V, W)) < 1e-5
+
+
+# ---- quantiser and mip pyramid (Resources.cpp:92-209) -------------------------------------------------
+def test_quantizer_border_and_truncation():
+    g = np.zeros((3, 4, 5), np.float32)
+    g[1, 2, 3] = 2.0
+    g[0, 0, 0] = 1.0
+    g[2, 3, 4] = 0.999 * 2.0
+    t = O.quantize_volume(g)
+    assert t.shape == (5, 6, 7)
+    assert t[0].max() == 0 and t[-1].max() == 0 and t[:, 0].max() == 0 and t[:, :, -1].max() == 0
+    assert t[2, 3, 4] == 255 and t[1, 1, 1] == 127 and t[3, 4, 5] == 254    # trunc(0.5*255)=127
+
+
+def test_mipmaps_analytic_9cube():
+    lvl0 = np.arange(9 * 9 * 9, dtype=np.uint32).reshape(9, 9, 9) % 251
+    lvl0 = lvl0.astype(np.uint8)
+    mips = O.generate_mipmaps(lvl0)
+    assert [m.shape for m in mips] == [(9, 9, 9), (4, 4, 4), (2, 2, 2), (1, 1, 1)]
+    assert np.array_equal(mips[0], lvl0)
+    blk = lvl0[:8, :8, :8].astype(np.uint16).reshape(4, 2, 4, 2, 4, 2).sum(axis=(1, 3, 5)) // 8
+    assert np.array_equal(mips[1], blk.astype(np.uint8))
+
+
+# ---- shadow volume (inScatter.cu:40-66) -----------------------------------------------------------------
+def test_inscatter_constant_cube_closed_form():
+    n = 16
+    tex = np.zeros((n, n, n), np.uint8)
+    tex[1:-1, 1:-1, 1:-1] = 255
+    # light travels along -z: transmittance at a texel is exp(-sigma * length of cloud above it)
+    o = O.Oracle(tex, 8, 8, light_direction=(0.0, 0.0, -1.0), cloud_size_m=20.0, mean_free_path_m=10.0)
+    ins = o.inscatter
+    sigma = 2.0
+    for z in (2, 5, 9, 13):
+        # voxel-corner sample position z/n; cloud occupies texels 1..n-2, i.e. box z in [1/n,(n-1)/n]
+        # (trilinear ramps of half a texel at both ends integrate to the same optical depth)
+        length = (n - 1) / n - z / n
+        expect = np.exp(-sigma * length)
+        got = ins[z, n // 2, n // 2] / 255.0
+        assert abs(got - expect) < 0.02, (z, got, expect)
+    # top border texel: its corner sits half-way down the trilinear ramp, 1/8 texel of optical depth
+    assert abs(ins[n - 1, n // 2, n // 2] / 255.0 - np.exp(-sigma * 0.125 / n)) < 0.02
+    assert ins[n - 1, 0, 0] == 255                                   # column outside the cloud: fully lit
+
+
+# ---- progressive / tonemap / convergence ---------------------------------------------------------------
+def test_welford_matches_numpy_statistics():
+    rng = np.random.default_rng(5)
+    frames = rng.random((12, 6, 7, 4), dtype=np.float32)
+    mean = np.zeros((6, 7, 4), np.float32)
+    m2 = np.zeros_like(mean)
+    for i, f in enumerate(frames, 1):
+        O.accumulate(np.ascontiguousarray(f), mean, m2, i)
+    assert np.allclose(mean, frames.mean(axis=0), atol=1e-6)
+    assert np.allclose(m2, ((frames - frames.mean(axis=0)) ** 2).sum(axis=0), atol=1e-4)
+
+
+def test_reinhard_properties():
+    rng = np.random.default_rng(6)
+    img = np.zeros((8, 8, 4), np.float32)
+    img[2:6, 2:6, :3] = rng.random((4, 4, 1), dtype=np.float32) * 3.0
+    img[..., 3] = 1.0
+    screen, avg = O.reinhard(img, 0.4)
+    lum = img[..., 0] * 0.265068 + img[..., 1] * 0.67023428 + img[..., 2] * 0.06409157
+    assert abs(avg - float((lum + 1e-5).mean())) < 1e-5
+    assert np.all(screen[..., 3] == 255)
+    # black pixels: 0 * (0/0) = NaN -> optix clamp(NaN,0,1) = fmaxf(0, fminf(NaN,1)) = 1 -> 255
+    assert np.all(screen[0, 0, :3] == 255)
+    # lit pixels follow Reinhard + gamma
+    y, x = 3, 3
+    lw = lum[y, x]
+    ld = lw * 0.4 / avg
+    ld = ld / (1 + ld)
+    expect = int(min(max(img[y, x, 0] * ld / lw, 0), 1) ** (1 / 2.2) * 255)
+    assert abs(int(screen[y, x, 0]) - expect) <= 1
+
+
+def test_convergence_rule():
+    mean = np.ones((40, 40, 4), np.float32)
+    m2 = np.zeros_like(mean)
+    assert O.is_converged(mean, m2, 99) == (False, 1600)          # < 100 subframes: never
+    assert O.is_converged(mean, m2, 100) == (True, 0)
+    m2[..., 0] = 100.0 * 100.0                                      # variance 100 -> wide interval
+    ok, bad = O.is_converged(mean, m2, 100)
+    assert not ok and bad == 1600
+    m2[:30, :, 0] = 0                                               # 400 bad pixels < 500 -> converged
+    ok, bad = O.is_converged(mean, m2, 100)
+    assert ok and bad == 400
+
+
+# ---- estimator: analytic known answers --------------------------------------------------------------------
+def test_background_is_exactly_zero_and_alpha_one():
+    tex = sphere_volume(24)
+    o = O.Oracle(tex, 16, 16, mode=0)
+    f = o.render_subframe(1)
+    assert np.all(f[..., 3] == 1.0)
+    assert np.all(f[0, :, :3] == 0) and np.all(f[:, 0, :3] == 0)   # corner rays miss the cloud
+    assert f[..., 0].max() > 0
+    assert np.array_equal(f[..., 0], f[..., 1]) and np.array_equal(f[..., 0], f[..., 2])   # white light
+
+
+def test_single_scatter_homogeneous_slab_closed_form():
+    """Mode SunSingleScatter on a constant-density cube with the sun behind the camera.  A ray that
+    crosses the cube collects  K * p(-1) * integral_0^L sigma exp(-sigma t) T_sun(t) dt  where the
+    light also enters through the camera-side face, T_sun(t) = exp(-sigma t), and the phase argument
+    dot(-lightDirection, dir) is -1 (back-scatter).  The shadow volume is computed at voxel CORNERS
+    (inScatter.cu:43-46) but fetched with texel-CENTRE addressing, i.e. it is read half a texel
+    deeper into the cloud: a factor exp(-sigma/(2n)) that this test includes."""
+    n = 24
+    tex = np.zeros((n, n, n), np.uint8)
+    tex[1:-1, 1:-1, 1:-1] = 255
+    eye = (2.5, 0.0, 0.0)
+    light = (-1.0, 0.0, 0.0)            # light travels -x, like the central view ray
+    sigma = 3.0                          # cloud_size / mean free path
+    o = O.Oracle(tex, 4, 4, mode=2, eye=eye, light_direction=light, cloud_size_m=30.0, mean_free_path_m=10.0)
+    U, V, W = O.camera_variables(eye, aspect=1.0, hfov=0.5)      # narrow fov: rays ~ parallel to -x
+    o.set_camera(eye, U, V, W)
+    spp = 4000
+    acc = 0.0
+    px, py = 2, 2                        # d = (0,0): the exact centre ray
+    for sid in range(1, spp + 1):
+        acc += float(o.render_subframe(sid, window=(px, py, px + 1, py + 1))[py, px, 0])
+    got = acc / spp
+    phase = float(O.mie_textures()[0][0])      # cos = -1 -> first texel (back-scatter)
+    L = (n - 2) / n                      # solid texels + two half-weight ramps
+    K = 1e6 * float(o.derived_uniforms()[13])
+    expect = K * phase * (1 - np.exp(-2 * sigma * L)) / 2 * np.exp(-sigma * 0.5 / n)
+    assert abs(got / expect - 1) < 0.04, (got, expect)

@@ -562,7 +562,8 @@ extern "C" int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint
     // split so that the scratch stays <= 4 GiB and sample / pixel indices fit 32 bits
     const uint64_t plane = (uint64_t)h->scene.width * h->scene.height;
     uint64_t cap = std::min<uint64_t>((4ull << 30) / (plane * sizeof(float4)), 0xffffffffull / std::max<uint64_t>(plane, 1));
-    cap = std::min<uint64_t>(cap, 0xffffffffull / (std::max<uint64_t>(h->n_tiles, 1) * 64ull));
+    // the work queue is a 32-bit counter that every wave bumps once more after it ran dry
+    cap = std::min<uint64_t>(cap, 0x7fffffffull / (std::max<uint64_t>(h->n_tiles, 1) * 64ull));
     cap = std::max<uint64_t>(std::min<uint64_t>(cap, 1024), 1);
     uint32_t done = 0;
     while (done < count) {

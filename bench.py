@@ -171,6 +171,7 @@ def main():
         "lookups_per_s": lookups / (render_ms * 1e-3) if render_ms > 0 else 0.0,
         "lookups_per_sample": lookups / max(dk["paths"], 1),
         "accumulate_ms_per_launch": (a1 - a0) / launches,
+        "counters_per_launch": {k: v / launches for k, v in dk.items()},
     }
 
     out = {

@@ -30,7 +30,7 @@ struct CtHandle_ {
     bool camera_set = false;
 
     // device memory
-    uint8_t *d_density = nullptr, *d_inscatter = nullptr;
+    uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr;
     uint2 *d_dcells = nullptr, *d_icells = nullptr;
     float *d_mie = nullptr, *d_chopped = nullptr, *d_cdf = nullptr;
     uint16_t *d_guide = nullptr;
@@ -176,7 +176,7 @@ static void release(CtHandle h)
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dcells, h->d_icells, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_tiles, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_tiles, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
         if (p) {
@@ -303,6 +303,20 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, launch_build_cells(h->d_density, nx, ny, nz, apron, h->d_dcells, h->stream));
     d.dcells = h->d_dcells;
     d.icells = h->d_icells;
+    {
+        // free-space distance field over 8^3 bricks (DevScene::dist)
+        const int bias = ((apron + 1 + 7) / 8) * 8;
+        const int gx = ((int)nx + 2 * bias + 7) / 8 + 1, gy = ((int)ny + 2 * bias + 7) / 8 + 1,
+                  gz = ((int)nz + 2 * bias + 7) / 8 + 1;
+        const size_t nb = (size_t)gx * gy * gz;
+        HIPCHK(h, dmalloc(&h->d_dist, nb));
+        HIPCHK(h, dmalloc(&h->d_dist_tmp, nb));
+        HIPCHK(h, launch_build_dist(h->d_density, nx, ny, nz, bias, gx, gy, gz, h->d_dist, h->d_dist_tmp, h->stream));
+        d.dist = h->d_dist;
+        d.dist_sy = gx;
+        d.dist_sz = gx * gy;
+        d.dist_bias = bias;
+    }
     HIPCHK(h, launch_inscatter(d, h->d_inscatter, h->stream));
     HIPCHK(h, launch_build_cells(h->d_inscatter, nx, ny, nz, apron, h->d_icells, h->stream));
 
@@ -363,9 +377,9 @@ extern "C" int ct_create(const CtScene *s, CtHandle *out)
     if (s->abi_version != CT_ABI_VERSION) {
         return fail(nullptr, CT_E_INVAL, "abi_version %u, library is %u", s->abi_version, CT_ABI_VERSION);
     }
-    if (!s->density_host || s->dims[0] < 2 || s->dims[1] < 2 || s->dims[2] < 2 || s->dims[0] > 4096 ||
-        s->dims[1] > 4096 || s->dims[2] > 4096) {
-        return fail(nullptr, CT_E_INVAL, "density volume missing or dims out of range [2,4096]");
+    if (!s->density_host || s->dims[0] < 2 || s->dims[1] < 2 || s->dims[2] < 2 || s->dims[0] > 2048 ||
+        s->dims[1] > 2048 || s->dims[2] > 2048) {
+        return fail(nullptr, CT_E_INVAL, "density volume missing or dims out of range [2,2048]");
     }
     if (s->mode < 0 || s->mode > 2) {
         return fail(nullptr, CT_E_INVAL, "Invalid Render Mode %d", s->mode); // CloudMaterial.cpp:62

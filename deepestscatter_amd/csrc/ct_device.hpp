@@ -54,6 +54,12 @@ struct DevScene {
     int32_t cell_sy;       // cells per row
     int32_t cell_sz;       // cells per slice
     int64_t cell_origin;   // index of cell (0,0,0)
+    // empty-space distance field over 8^3-texel bricks: dist[brick] = Chebyshev distance (in
+    // bricks, capped) to the nearest brick that is not provably "free" (all texels a trilinear
+    // footprint based in it can touch are zero AND every position in it passes isInBox).
+    const uint8_t *dist;
+    int32_t dist_sy, dist_sz; // bricks per row / slice
+    int32_t dist_bias;        // texel offset added before >>3 (multiple of 8, >= apron)
     int32_t nx, ny, nz;    // texels
     float sx, sy, sz;      // box coordinate -> texel coordinate (textureScale * N)
     float bx, by, bz;      // bboxSize          (VDBCloud.cpp:104)
@@ -119,15 +125,35 @@ CT_DEV float filter_cell(uint2 c, float wx, float wy, float wz)
     return fmaf(wz, c1 - c0, c0) * (1.0f / 255.0f);
 }
 
+// (int)floorf(x) in one instruction (v_cvt_flr_i32_f32); identical for every in-range x.
+CT_DEV int32_t floor_to_int(float x)
+{
+    int32_t r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // tex3D for positions the tracer can reach (inside the slack box +- one step): no clamp, the
 // apron supplies clamp-to-edge.
 CT_DEV float tex3_apron(const DevScene &sc, const uint2 *cells, f3 p)
 {
     const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
-    const float flx = floorf(x), fly = floorf(y), flz = floorf(z);
-    const int32_t ix = (int32_t)flx, iy = (int32_t)fly, iz = (int32_t)flz;
-    const int64_t idx = sc.cell_origin + (int64_t)(iz * sc.cell_sz + iy * sc.cell_sy + ix);
-    const uint2 c = cells[idx];
+    const int32_t ix = floor_to_int(x), iy = floor_to_int(y), iz = floor_to_int(z);
+    const int32_t rel = __mul24(iz, sc.cell_sz) + __mul24(iy, sc.cell_sy) + ix;
+    const uint2 c = cells[sc.cell_origin + (int64_t)rel];
+    return filter_cell(c, fract_(x), fract_(y), fract_(z));
+}
+
+// The same fetch for the march, which also wants the free-space distance of the brick the
+// position falls in (both loads are issued together, so the distance costs no extra latency).
+CT_DEV float tex3_apron_dist(const DevScene &sc, const uint2 *cells, f3 p, uint32_t &dist_out)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    const int32_t ix = floor_to_int(x), iy = floor_to_int(y), iz = floor_to_int(z);
+    const int32_t rel = __mul24(iz, sc.cell_sz) + __mul24(iy, sc.cell_sy) + ix;
+    const int32_t bx = (ix + sc.dist_bias) >> 3, by = (iy + sc.dist_bias) >> 3, bz = (iz + sc.dist_bias) >> 3;
+    const uint2 c = cells[sc.cell_origin + (int64_t)rel];
+    dist_out = sc.dist[__mul24(bz, sc.dist_sz) + __mul24(by, sc.dist_sy) + bx];
     return filter_cell(c, fract_(x), fract_(y), fract_(z));
 }
 

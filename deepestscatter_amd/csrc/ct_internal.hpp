@@ -36,6 +36,8 @@ __host__ __device__ inline uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_
 
 hipError_t launch_build_cells(const uint8_t *texels, int nx, int ny, int nz, int apron, uint2 *cells,
                               hipStream_t stream);
+hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
+                             uint8_t *dist, uint8_t *scratch, hipStream_t stream);
 hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream);
 hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_t shard_index,

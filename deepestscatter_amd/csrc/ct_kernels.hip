@@ -12,6 +12,8 @@
 //   converged_kernel           Camera::isConverged (Camera.cpp:232-268)
 //
 // Compile with -ffp-contract=off: results must be bit-identical to oracle/ct_oracle.c.
+#include <cstdlib>
+
 #include "ct_internal.hpp"
 
 namespace ct {
@@ -49,6 +51,90 @@ hipError_t launch_build_cells(const uint8_t *texels, int nx, int ny, int nz, int
     const int blocks = (int)((total + threads - 1) / threads < 16384 ? (total + threads - 1) / threads : 16384);
     hipLaunchKernelGGL(build_cells_kernel, dim3(blocks), dim3(threads), 0, stream, texels, nx, ny, nz, apron, cells,
                        cx, cy, cz);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// free-space distance field over 8^3-texel bricks (see DevScene::dist)
+// =============================================================================================
+constexpr int kBrick = 8;
+constexpr int kDistMax = 24;
+
+// dist = kDistMax for free bricks, 0 otherwise.  A brick is free when every texel a trilinear
+// footprint based inside it can read ([lo-1, hi+1]^3) is zero and its texel range lies in
+// [1, N-3] on every axis, which implies isInBox for every position whose base texel is in it.
+__global__ void brick_free_kernel(const uint8_t *__restrict__ t, int nx, int ny, int nz, int bias, int gx, int gy,
+                                  int gz, uint8_t *__restrict__ dist)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= gx * gy * gz) {
+        return;
+    }
+    const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
+    const int x0 = bx * kBrick - bias, y0 = by * kBrick - bias, z0 = bz * kBrick - bias;
+    bool free_ = x0 >= 1 && y0 >= 1 && z0 >= 1 && x0 + kBrick - 1 <= nx - 3 && y0 + kBrick - 1 <= ny - 3 &&
+                 z0 + kBrick - 1 <= nz - 3;
+    if (free_) {
+        for (int z = z0 - 1; z <= z0 + kBrick && free_; z++) {
+            for (int y = y0 - 1; y <= y0 + kBrick && free_; y++) {
+                const uint8_t *row = t + ((size_t)z * ny + y) * nx;
+                for (int x = x0 - 1; x <= x0 + kBrick; x++) {
+                    if (row[x] != 0) {
+                        free_ = false;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    dist[b] = free_ ? (uint8_t)kDistMax : (uint8_t)0;
+}
+
+// One relaxation of the Chebyshev distance transform: d = min(d, 1 + min over the 26 neighbours).
+__global__ void brick_dist_relax_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int gx, int gy,
+                                        int gz)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= gx * gy * gz) {
+        return;
+    }
+    const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
+    int m = 255;
+    for (int dz = -1; dz <= 1; dz++) {
+        for (int dy = -1; dy <= 1; dy++) {
+            for (int dx = -1; dx <= 1; dx++) {
+                const int x = bx + dx, y = by + dy, z = bz + dz;
+                const int v = (x < 0 || y < 0 || z < 0 || x >= gx || y >= gy || z >= gz)
+                                  ? 0
+                                  : (int)in[((size_t)z * gy + y) * gx + x];
+                m = min(m, v);
+            }
+        }
+    }
+    out[b] = (uint8_t)min((int)in[b], m + 1);
+}
+
+hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
+                             uint8_t *dist, uint8_t *scratch, hipStream_t stream)
+{
+    const int total = gx * gy * gz;
+    const int threads = 256, blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(brick_free_kernel, dim3(blocks), dim3(threads), 0, stream, texels, nx, ny, nz, bias, gx, gy,
+                       gz, dist);
+    // kDistMax relaxations make every value exact up to the cap; ping-pong, ending in `dist`
+    uint8_t *a = dist, *b = scratch;
+    for (int i = 0; i < kDistMax; i++) {
+        hipLaunchKernelGGL(brick_dist_relax_kernel, dim3(blocks), dim3(threads), 0, stream, a, b, gx, gy, gz);
+        uint8_t *tmp = a;
+        a = b;
+        b = tmp;
+    }
+    if (a != dist) {
+        hipError_t e = hipMemcpyAsync(dist, a, (size_t)total, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
     return hipGetLastError();
 }
 
@@ -101,9 +187,10 @@ hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream
 // =============================================================================================
 // the estimator
 // =============================================================================================
+// LDS holds what the CDF inversion reads ~5 times per scatter; the two phase tables are read
+// once per scatter and stay in global memory (L1/L2 resident, 16 KiB each).
 struct MieLds {
     float cdf[kMieN];
-    float chopped[kMieN];
     uint16_t guide[kGuideN + 2];
 };
 
@@ -111,7 +198,6 @@ CT_DEV void load_tables(const DevScene &sc, MieLds &lds)
 {
     for (int i = threadIdx.x; i < kMieN; i += blockDim.x) {
         lds.cdf[i] = sc.cdf[i];
-        lds.chopped[i] = sc.chopped[i];
     }
     for (int i = threadIdx.x; i < kGuideN + 2; i += blockDim.x) {
         lds.guide[i] = sc.guide[i];
@@ -129,11 +215,12 @@ CT_DEV f3 primary_direction(const DevScene &sc, uint32_t x, uint32_t y)
 }
 
 // NEE: getInScattering, cloud.cuh:146-158.
-CT_DEV f3 in_scattering(const DevScene &sc, const MieLds &lds, f3 pos, f3 dir, bool chopped)
+CT_DEV f3 in_scattering(const DevScene &sc, f3 pos, f3 dir, bool chopped)
 {
     const float cos_light = dot3(mk3(sc.nlx, sc.nly, sc.nlz), dir);
     const float u = (cos_light + 1) / 2;
-    const float phase = chopped ? tex1(lds.chopped, u) : tex1(sc.mie, u);
+    const float *table = chopped ? sc.chopped : sc.mie;
+    const float phase = tex1(table, u);
     const float ins = tex3_apron(sc, sc.icells, pos);
     f3 l = scale3(mk3(sc.lr, sc.lg, sc.lb), ins);
     l = scale3(l, phase);
@@ -141,6 +228,14 @@ CT_DEV f3 in_scattering(const DevScene &sc, const MieLds &lds, f3 pos, f3 dir, b
 }
 
 enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_BOUNCE = 2 };
+
+// 1 / max per-axis advance of one march step, in texels (approximate reciprocal is fine: it only
+// sizes a conservative skip, see the free-space skip in the march phase).
+CT_DEV float inv_max_advance(const DevScene &sc, f3 stepv)
+{
+    const float m = fmaxf(fmaxf(fabsf(stepv.x) * sc.sx, fabsf(stepv.y) * sc.sy), fabsf(stepv.z) * sc.sz);
+    return __builtin_amdgcn_rcpf(fmaxf(m, 1e-20f));
+}
 
 constexpr uint32_t kChunk = 512;    // samples a wave takes from the global queue at once
 constexpr uint32_t kRegenMin = 8;   // idle lanes that trigger a regeneration phase
@@ -165,6 +260,8 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
     f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), stepv = mk3(0, 0, 0), rad = mk3(0, 0, 0);
     uint32_t seed = 0, depth = 0, out_idx = 0;
     float xi = 0, T = 1;
+    uint32_t dfree = 0;     // free-space distance of the brick `pos` is in (0 = unknown / none)
+    float inv_maxd = 0;     // 1 / (largest per-axis texel advance of one step)
     int state = ST_IDLE;
 
     // wave-uniform bookkeeping (lives in SGPRs)
@@ -236,6 +333,8 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                                 xi = u24_to_float(lcg24(seed));
                                 T = 1;
                                 stepv = scale3(dir, sc.sample_step);
+                                inv_maxd = inv_max_advance(sc, stepv);
+                                dfree = 0;
                                 state = ST_MARCH;
                             } else {
                                 ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
@@ -261,7 +360,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             // ---------------- scatter: NEE + new direction (cloudRadianceMaterials.cu:53-61) ----------------
             if (state == ST_BOUNCE) {
                 const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
-                rad = add3(rad, in_scattering(sc, lds, pos, dir, chopped));
+                rad = add3(rad, in_scattering(sc, pos, dir, chopped));
                 c_il += 1;
                 bool go = (MODE != 2);
                 if (go) {
@@ -276,6 +375,8 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                     xi = u24_to_float(lcg24(seed));
                     T = 1;
                     stepv = scale3(dir, sc.sample_step);
+                    inv_maxd = inv_max_advance(sc, stepv);
+                    dfree = 0;
                     state = ST_MARCH;
                 } else {
                     ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
@@ -285,8 +386,20 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         } else {
             // ---------------- march one step (getNextScatteringEvent, cloud.cuh:87-105) ----------------
             if (state == ST_MARCH) {
+                // Free-space skip: every brick within Chebyshev distance dfree-1 of the one `pos` is
+                // in is free, so the next n steps can neither collide (all 8 texels are 0, T *= 1)
+                // nor leave the box; only the position updates have to be replayed (same float adds
+                // in the same order -> bit-identical path).  They still count as density lookups:
+                // the counter is the algorithm's lookup count, not the loads this kernel issued.
+                if (dfree > 1u) {
+                    const int n = (int)(((float)(kBrick * (int)(dfree - 1u)) - 0.5f) * inv_maxd);
+                    for (int i = 0; i < n; i++) {
+                        pos = add3(pos, stepv);
+                    }
+                    c_dl += (uint32_t)n;
+                }
                 pos = add3(pos, stepv);
-                const float density = tex3_apron(sc, sc.dcells, pos) * sc.density_multiplier;
+                const float density = tex3_apron_dist(sc, sc.dcells, pos, dfree) * sc.density_multiplier;
                 c_dl += 1;
                 const float extinction = density * sc.sample_step;
                 T *= expf_inrange(-extinction);
@@ -334,7 +447,13 @@ LaunchShape persistent_shape(int device)
     hipDeviceProp_t prop;
     LaunchShape s{ 1024, 256 };
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
-        s.blocks = prop.multiProcessorCount * 4; // 4 x 256 threads per CU: LDS 40 KiB/block
+        s.blocks = prop.multiProcessorCount * 6; // 6 x 256 threads per CU: LDS 24 KiB/block
+        if (const char *e = getenv("CT_BLOCKS_PER_CU")) {   // tuning knob for experiments
+            const int v = atoi(e);
+            if (v >= 1 && v <= 8) {
+                s.blocks = prop.multiProcessorCount * v;
+            }
+        }
     }
     return s;
 }
@@ -425,7 +544,7 @@ __global__ __launch_bounds__(256) void render_simple_kernel(DevScene sc, BatchAr
                 break;
             }
             const bool chopped = (sc.mode == 1) ? true : (sc.mode == 0 ? (depth != 1) : false);
-            rad = add3(rad, in_scattering(sc, lds, pos, dir, chopped));
+            rad = add3(rad, in_scattering(sc, pos, dir, chopped));
             c_il++;
             if (sc.mode == 2) {
                 break;

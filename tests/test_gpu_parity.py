@@ -105,6 +105,32 @@ def test_ragged_frame_and_noncubic_volume():
     tr.close()
 
 
+@pytest.mark.parametrize("dims,radius", [((64, 64, 64), 0.16), ((96, 72, 80), 0.12)])
+def test_free_space_skipping_is_bit_exact(dims, radius):
+    """Small cloud in a big box: most bricks are free, so the march replays position updates
+    without fetching.  Radiance AND the algorithmic lookup counters must still equal the oracle's
+    (which fetches at every step) and the plain one-thread-per-pixel kernel's."""
+    tex = sphere_volume(dims=dims, radius=radius, seed=21)
+    w, h = 48, 40
+    tr, orc = make_pair(tex, w, h, mode=0)
+    mean, m2 = orc.render(3)
+    tr.render_accumulate(1, 3)
+    assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2)
+    assert tr.counters() == orc.counters.as_dict()
+    plain = ds.CloudTracer(tex, width=w, height=h, mode=0, flags=_lib.CT_FLAG_SIMPLE_KERNEL)
+    plain.render_accumulate(1, 3)
+    assert np.array_equal(plain.mean(), mean) and plain.counters() == tr.counters()
+    # other view directions exercise the other axes of the skip bound
+    for eye in ((0.2, 2.4, 0.3), (-0.5, -0.3, -2.3)):
+        U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
+        tr.set_camera(eye, U, V, W)
+        orc.set_camera(eye, U, V, W)
+        tr.render_subframe(5)
+        assert np.array_equal(tr.frame(), orc.render_subframe(5))
+    tr.close()
+    plain.close()
+
+
 def test_simple_kernel_equals_persistent_kernel():
     tex = sphere_volume(32, seed=6)
     a = ds.CloudTracer(tex, width=40, height=32, mode=0)

@@ -174,6 +174,8 @@ def main():
         "counters_per_launch": {k: v / launches for k, v in dk.items()},
     }
 
+    if os.environ.get("CT_STATS"):
+        roofline["scheduler_stats"] = tr.debug_stats()
     out = {
         "metric": "Msamples/s (rays x spp) at 512^3 vol, 1024^2 frame; HBM GB/s vs roofline",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -258,6 +258,14 @@ class CloudTracer:
     def set_stream(self, hip_stream: int | None):
         check(self.L.ct_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None), self.h)
 
+    def debug_stats(self) -> dict:
+        """Scheduler diagnostics (only filled when the process runs with CT_STATS=1)."""
+        out = np.zeros(16, np.uint64)
+        check(self.L.ct_debug_stats(self.h, _p(out)), self.h)
+        names = ["regen_phases", "regen_lanes", "march_phases", "march_lanes", "scatter_phases", "scatter_lanes",
+                 "fetched_steps", "fetched_zero_cells", "skipped_steps"]
+        return {n: int(v) for n, v in zip(names, out)}
+
     def debug_cdf_inversion(self, first_u24: int, count: int) -> np.ndarray:
         out = np.empty(count, np.uint32)
         check(self.L.ct_debug_cdf_inversion(self.h, first_u24, count, _p(out)), self.h)

@@ -38,10 +38,20 @@ struct CtHandle_ {
     uchar4 *d_screen = nullptr;
     float4 *d_frames = nullptr; // batch scratch [S][H][W]
     uint32_t frames_capacity = 0; // in subframes
-    uint32_t *d_tiles = nullptr;
-    uint32_t n_tiles = 0;
+    // work queue of the persistent kernel (rebuilt when the camera moves)
+    float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
+    uint32_t *d_pixels = nullptr;     // this shard's box-hitting pixels, padded to groups of 64
+    uint32_t *d_cost = nullptr;       // measured cost per group (sum of path depths)
+    uint32_t *d_job_group = nullptr, *d_job_sub = nullptr; // job list of the current batch size
+    uint32_t n_groups = 0, groups_capacity = 0;
+    uint32_t n_jobs = 0, jobs_capacity = 0, jobs_S = 0;
+    uint64_t own_pixels = 0, hit_pixels = 0;
+    bool queue_dirty = true, order_tuned = false;
+    std::vector<uint32_t> group_order;   // groups, most expensive first (identity until tuned)
+    std::vector<float> group_depth;      // measured mean path depth per group (0 until tuned)
+    unsigned long long host_paths = 0, host_hits = 0; // paths / box hits of the persistent path
     uint32_t *d_queue = nullptr;
-    unsigned long long *d_counters = nullptr; // kCounterCount + 1 (unconverged)
+    unsigned long long *d_counters = nullptr; // kCounterCount + 1 (unconverged) + kStatCount
     float *d_colsum = nullptr, *d_avg = nullptr;
 
     size_t volume_bytes = 0;
@@ -176,7 +186,7 @@ static void release(CtHandle h)
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dcells, h->d_icells, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_tiles, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_primary, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
         if (p) {
@@ -304,10 +314,10 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.dcells = h->d_dcells;
     d.icells = h->d_icells;
     {
-        // free-space distance field over 8^3 bricks (DevScene::dist)
-        const int bias = ((apron + 1 + 7) / 8) * 8;
-        const int gx = ((int)nx + 2 * bias + 7) / 8 + 1, gy = ((int)ny + 2 * bias + 7) / 8 + 1,
-                  gz = ((int)nz + 2 * bias + 7) / 8 + 1;
+        // free-space distance field over kBrick^3 bricks (DevScene::dist)
+        const int bias = ((apron + 1 + kBrick - 1) / kBrick) * kBrick;
+        const int gx = ((int)nx + 2 * bias + kBrick - 1) / kBrick + 1, gy = ((int)ny + 2 * bias + kBrick - 1) / kBrick + 1,
+                  gz = ((int)nz + 2 * bias + kBrick - 1) / kBrick + 1;
         const size_t nb = (size_t)gx * gy * gz;
         HIPCHK(h, dmalloc(&h->d_dist, nb));
         HIPCHK(h, dmalloc(&h->d_dist_tmp, nb));
@@ -329,33 +339,14 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, dmalloc(&h->d_colsum, s->width));
     HIPCHK(h, dmalloc(&h->d_avg, 1));
     HIPCHK(h, dmalloc(&h->d_queue, 1));
-    HIPCHK(h, dmalloc(&h->d_counters, kCounterCount + 1));
+    HIPCHK(h, dmalloc(&h->d_counters, kCounterCount + 1 + kStatCount));
     HIPCHK(h, hipMemsetAsync(h->d_frame, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_mean, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_m2, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_screen, 0, pixels * sizeof(uchar4), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1) * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1 + kStatCount) * sizeof(unsigned long long), h->stream));
 
-    // ---- this shard's tiles, Morton order (neighbouring chunks of the queue stay close in the volume)
-    std::vector<std::pair<uint32_t, uint32_t>> order;
-    for (uint32_t ty = 0; ty < d.tiles_y; ty++) {
-        for (uint32_t tx = 0; tx < d.tiles_x; tx++) {
-            if (tile_owner(tx, ty, s->shard_count) == s->shard_index) {
-                order.emplace_back(morton2(tx, ty), ty * d.tiles_x + tx);
-            }
-        }
-    }
-    std::sort(order.begin(), order.end());
-    std::vector<uint32_t> tiles(order.size());
-    for (size_t i = 0; i < order.size(); i++) {
-        tiles[i] = order[i].second;
-    }
-    h->n_tiles = (uint32_t)tiles.size();
-    HIPCHK(h, dmalloc(&h->d_tiles, std::max<size_t>(tiles.size(), 1)));
-    if (!tiles.empty()) {
-        HIPCHK(h, hipMemcpyAsync(h->d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                                 h->stream));
-    }
+    HIPCHK(h, dmalloc(&h->d_primary, 2 * pixels));
     HIPCHK(h, hipStreamSynchronize(h->stream));
 
     // ---- default pose: Camera.cpp:37-39 through sutil::calculateCameraVariables
@@ -459,6 +450,155 @@ extern "C" int ct_set_camera(CtHandle h, const float eye[3], const float U[3], c
     d.vx = V[0]; d.vy = V[1]; d.vz = V[2];
     d.wx = W[0]; d.wy = W[1]; d.wz = W[2];
     h->camera_set = true;
+    h->queue_dirty = true; // primary rays and the work queue depend on the pose
+    return CT_OK;
+}
+
+// Primary rays of the current pose + the list of this shard's pixels that hit the box, in
+// tile-Morton order, cut into groups of 64 (one wave's worth).
+static int rebuild_queue(CtHandle h)
+{
+    const uint32_t W = h->scene.width, H = h->scene.height;
+    const size_t pixels = (size_t)W * H;
+    HIPCHK(h, launch_primary_rays(h->dev, h->d_primary, h->stream));
+    std::vector<float4> prim(2 * pixels);
+    HIPCHK(h, hipMemcpyAsync(prim.data(), h->d_primary, prim.size() * sizeof(float4), hipMemcpyDeviceToHost,
+                             h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t tiles_x = h->dev.tiles_x, tiles_y = h->dev.tiles_y;
+    std::vector<std::pair<uint32_t, uint32_t>> tiles;
+    for (uint32_t ty = 0; ty < tiles_y; ty++) {
+        for (uint32_t tx = 0; tx < tiles_x; tx++) {
+            if (tile_owner(tx, ty, h->scene.shard_count) == h->scene.shard_index) {
+                tiles.emplace_back(morton2(tx, ty), ty * tiles_x + tx);
+            }
+        }
+    }
+    std::sort(tiles.begin(), tiles.end());
+    std::vector<uint32_t> list;
+    list.reserve(pixels / std::max(1u, h->scene.shard_count) + 64);
+    uint64_t own = 0;
+    for (const auto &t : tiles) {
+        const uint32_t ty = t.second / tiles_x, tx = t.second - ty * tiles_x;
+        for (uint32_t l = 0; l < 64; l++) {
+            const uint32_t x = tx * kTile + (l & 7u), y = ty * kTile + (l >> 3);
+            if (x < W && y < H) {
+                own++;
+                const uint32_t p = y * W + x;
+                if (prim[2 * (size_t)p].w != 0.f) {
+                    list.push_back(p);
+                }
+            }
+        }
+    }
+    h->own_pixels = own;
+    h->hit_pixels = list.size();
+    while (list.size() % 64 != 0) {
+        list.push_back(0xffffffffu);
+    }
+    h->n_groups = (uint32_t)(list.size() / 64);
+    if (h->n_groups > h->groups_capacity) {
+        for (void *p : { (void *)h->d_pixels, (void *)h->d_cost }) {
+            if (p) {
+                HIPCHK(h, hipFree(p));
+            }
+        }
+        h->d_pixels = h->d_cost = nullptr;
+        HIPCHK(h, dmalloc(&h->d_pixels, (size_t)h->n_groups * 64));
+        HIPCHK(h, dmalloc(&h->d_cost, h->n_groups));
+        h->groups_capacity = h->n_groups;
+    }
+    h->group_order.resize(h->n_groups);
+    for (uint32_t i = 0; i < h->n_groups; i++) {
+        h->group_order[i] = i;
+    }
+    h->group_depth.assign(h->n_groups, 0.f);
+    if (h->n_groups) {
+        HIPCHK(h, hipMemcpyAsync(h->d_pixels, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                 h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_cost, 0, h->n_groups * sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->queue_dirty = false;
+    h->order_tuned = false;
+    h->jobs_S = 0; // force a new job list
+    return CT_OK;
+}
+
+// Job list for batches of S subframes.  A job is (group, subframe range); its length is chosen
+// so that a job's expected serial work per lane stays bounded: groups whose paths are deep get
+// one-subframe jobs, cheap groups up to 8 subframes per job.
+static int build_jobs(CtHandle h, uint32_t S)
+{
+    if (h->jobs_S == S) {
+        return CT_OK;
+    }
+    std::vector<uint32_t> jg, js;
+    jg.reserve((size_t)h->n_groups * ((S + 7) / 8));
+    js.reserve(jg.capacity());
+    for (uint32_t g : h->group_order) {
+        const float d = h->group_depth[g];
+        uint32_t len = 8;
+        if (d > 0.f) {
+            len = (uint32_t)std::min(8.f, std::max(1.f, 256.f / d));
+        }
+        for (uint32_t s0 = 0; s0 < S; s0 += len) {
+            jg.push_back(g);
+            js.push_back(s0 | (std::min(len, S - s0) << 16));
+        }
+    }
+    h->n_jobs = (uint32_t)jg.size();
+    if (h->n_jobs > h->jobs_capacity) {
+        for (void *p : { (void *)h->d_job_group, (void *)h->d_job_sub }) {
+            if (p) {
+                HIPCHK(h, hipFree(p));
+            }
+        }
+        h->d_job_group = h->d_job_sub = nullptr;
+        h->jobs_capacity = h->n_jobs + h->n_jobs / 4;
+        HIPCHK(h, dmalloc(&h->d_job_group, h->jobs_capacity));
+        HIPCHK(h, dmalloc(&h->d_job_sub, h->jobs_capacity));
+    }
+    if (h->n_jobs) {
+        HIPCHK(h, hipMemcpyAsync(h->d_job_group, jg.data(), jg.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                 h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_job_sub, js.data(), js.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                 h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->jobs_S = S;
+    return CT_OK;
+}
+
+// Longest-processing-time-first: visit the groups whose paths were deepest first, so that the
+// 2000-bounce paths start at the head of the launch instead of becoming its tail.  Groups of
+// the same cost class (power of two) keep their Morton order for cache locality.  The order and
+// the job lengths only change the schedule, never a result.
+static int tune_order(CtHandle h, uint32_t measured_subframes)
+{
+    h->order_tuned = true;
+    if (h->n_groups < 2 || measured_subframes == 0) {
+        return CT_OK;
+    }
+    std::vector<uint32_t> cost(h->n_groups);
+    HIPCHK(h, hipMemcpyAsync(cost.data(), h->d_cost, cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    auto cls = [&](uint32_t g) {
+        uint32_t c = cost[g], k = 0;
+        while (c) {
+            k++;
+            c >>= 1;
+        }
+        return k;
+    };
+    for (uint32_t g = 0; g < h->n_groups; g++) {
+        h->group_order[g] = g;
+        h->group_depth[g] = (float)cost[g] / (64.f * (float)measured_subframes);
+    }
+    std::stable_sort(h->group_order.begin(), h->group_order.end(),
+                     [&](uint32_t a, uint32_t b) { return cls(a) > cls(b); });
+    h->jobs_S = 0; // rebuild the job list with the new order
     return CT_OK;
 }
 
@@ -481,34 +621,54 @@ static int ensure_frames(CtHandle h, uint32_t S)
 // One launch of the estimator over S subframes into `frames` (+ optional accumulate).
 static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, bool accumulate)
 {
+    const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
+    if (!simple && h->queue_dirty) {
+        const int rc = rebuild_queue(h);
+        if (rc != CT_OK) {
+            return rc;
+        }
+    }
+    if (!simple) {
+        const int rc = build_jobs(h, S);
+        if (rc != CT_OK) {
+            return rc;
+        }
+    }
     BatchArgs ba{};
     ba.frames = frames;
-    ba.tiles = h->d_tiles;
-    ba.n_tiles = h->n_tiles;
+    ba.primary = h->d_primary;
+    ba.pixels = h->d_pixels;
+    ba.job_group = h->d_job_group;
+    ba.job_sub = h->d_job_sub;
+    ba.cost = h->d_cost;
+    ba.n_jobs = h->n_jobs;
     ba.first_subframe = first;
     ba.S = S;
-    ba.total = h->n_tiles * S * 64u;
     ba.queue = h->d_queue;
     ba.counters = h->d_counters;
+    ba.stats = h->d_counters + kCounterCount + 1;
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(uint32_t), h->stream));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-    if (h->n_tiles != 0) {
-        if (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) {
-            for (uint32_t s = 0; s < S; s++) {
-                BatchArgs one = ba;
-                one.frames = frames + (size_t)s * h->scene.width * h->scene.height;
-                one.first_subframe = first + s;
-                one.S = 1;
-                HIPCHK(h, launch_render_simple(h->dev, one, h->scene.shard_index, h->scene.shard_count, h->stream));
-            }
-        } else {
+    if (simple) {
+        for (uint32_t s = 0; s < S; s++) {
+            BatchArgs one = ba;
+            one.frames = frames + (size_t)s * h->scene.width * h->scene.height;
+            one.first_subframe = first + s;
+            one.S = 1;
+            HIPCHK(h, launch_render_simple(h->dev, one, h->scene.shard_index, h->scene.shard_count, h->stream));
+        }
+    } else {
+        if (h->n_jobs != 0) {
             HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
         }
+        h->host_paths += h->own_pixels * S;
+        h->host_hits += h->hit_pixels * S;
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if (accumulate) {
-        HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, first, S, h->scene.width, h->scene.height,
-                                          h->scene.shard_index, h->scene.shard_count, h->stream));
+        HIPCHK(h, launch_accumulate_batch(frames, simple ? nullptr : h->d_primary, h->d_mean, h->d_m2, first, S,
+                                          h->scene.width, h->scene.height, h->scene.shard_index,
+                                          h->scene.shard_count, h->stream));
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev[2]));
@@ -518,6 +678,9 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
     h->render_ms += ms01;
     h->accum_ms += ms12;
     h->launches += 1;
+    if (!simple && !h->order_tuned) {
+        return tune_order(h, S);
+    }
     return CT_OK;
 }
 
@@ -528,8 +691,9 @@ extern "C" int ct_render_subframe(CtHandle h, uint32_t subframe_id, float *frame
         return fail(h, CT_E_STATE, "ct_set_camera has not been called");
     }
     const size_t bytes = (size_t)h->scene.width * h->scene.height * sizeof(float4);
-    // pixels of other shards (and nothing else) stay (0,0,0,0)
-    HIPCHK(h, hipMemsetAsync(h->d_frame, 0, bytes, h->stream));
+    // own pixels start as a miss (0,0,0,1); pixels of other shards stay (0,0,0,0)
+    HIPCHK(h, launch_fill_frame(h->d_frame, h->scene.width, h->scene.height, h->scene.shard_index,
+                                h->scene.shard_count, h->stream));
     const int rc = run_batch(h, h->d_frame, subframe_id, 1, false);
     if (rc != CT_OK) {
         return rc;
@@ -549,7 +713,7 @@ extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *fram
     }
     const float4 *src = frame_rgba_dev ? (const float4 *)frame_rgba_dev : h->d_frame;
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    HIPCHK(h, launch_accumulate_batch(src, h->d_mean, h->d_m2, subframe_id, 1, h->scene.width, h->scene.height,
+    HIPCHK(h, launch_accumulate_batch(src, nullptr, h->d_mean, h->d_m2, subframe_id, 1, h->scene.width, h->scene.height,
                                       h->scene.shard_index, h->scene.shard_count, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev[2]));
@@ -577,7 +741,13 @@ extern "C" int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint
     const uint64_t plane = (uint64_t)h->scene.width * h->scene.height;
     uint64_t cap = std::min<uint64_t>((4ull << 30) / (plane * sizeof(float4)), 0xffffffffull / std::max<uint64_t>(plane, 1));
     // the work queue is a 32-bit counter that every wave bumps once more after it ran dry
-    cap = std::min<uint64_t>(cap, 0x7fffffffull / (std::max<uint64_t>(h->n_tiles, 1) * 64ull));
+    if (h->queue_dirty && !(h->scene.flags & CT_FLAG_SIMPLE_KERNEL)) {
+        const int rc = rebuild_queue(h);
+        if (rc != CT_OK) {
+            return rc;
+        }
+    }
+    cap = std::min<uint64_t>(cap, 0xffffull); // job_sub packs the subframe offset in 16 bits
     cap = std::max<uint64_t>(std::min<uint64_t>(cap, 1024), 1);
     uint32_t done = 0;
     while (done < count) {
@@ -603,11 +773,12 @@ extern "C" int ct_reset(CtHandle h)
     HIPCHK(h, hipMemsetAsync(h->d_frame, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_mean, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_m2, 0, pixels * sizeof(float4), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1) * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1 + kStatCount) * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->subframes = 0;
     h->render_ms = h->accum_ms = 0;
     h->launches = 0;
+    h->host_paths = h->host_hits = 0;
     return CT_OK;
 }
 
@@ -749,8 +920,8 @@ extern "C" int ct_counters(CtHandle h, CtCounters *out)
     unsigned long long c[kCounterCount];
     HIPCHK(h, hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    out->paths = c[0];
-    out->box_hits = c[1];
+    out->paths = c[0] + h->host_paths;
+    out->box_hits = c[1] + h->host_hits;
     out->density_lookups = c[2];
     out->inscatter_lookups = c[3];
     out->scatter_events = c[4];
@@ -769,6 +940,21 @@ extern "C" int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumul
     }
     if (launches_out) {
         *launches_out = h->launches;
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_debug_stats(CtHandle h, uint64_t out[16])
+{
+    NEED(h);
+    if (!out) {
+        return fail(h, CT_E_INVAL, "out is NULL");
+    }
+    unsigned long long c[kStatCount];
+    HIPCHK(h, hipMemcpyAsync(c, h->d_counters + kCounterCount + 1, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < kStatCount; i++) {
+        out[i] = c[i];
     }
     return CT_OK;
 }

@@ -43,6 +43,8 @@ constexpr float kPi = 3.14159265358979323846f;
 constexpr int kMieN = 4096;           // entries per Mie table (Mie.cpp:8-8203)
 constexpr int kGuideN = 4096;         // buckets of the CDF guide table
 constexpr float kFracMax = 0x1.fffffep-1f;
+constexpr int kBrick = 4;             // texels per edge of a free-space brick
+constexpr int kBrickShift = 2;
 
 // All uniforms of the path: the OptiX variable scopes of SURVEY section 8b, flattened.
 struct DevScene {
@@ -54,12 +56,12 @@ struct DevScene {
     int32_t cell_sy;       // cells per row
     int32_t cell_sz;       // cells per slice
     int64_t cell_origin;   // index of cell (0,0,0)
-    // empty-space distance field over 8^3-texel bricks: dist[brick] = Chebyshev distance (in
+    // empty-space distance field over kBrick^3-texel bricks: dist[brick] = Chebyshev distance (in
     // bricks, capped) to the nearest brick that is not provably "free" (all texels a trilinear
     // footprint based in it can touch are zero AND every position in it passes isInBox).
     const uint8_t *dist;
     int32_t dist_sy, dist_sz; // bricks per row / slice
-    int32_t dist_bias;        // texel offset added before >>3 (multiple of 8, >= apron)
+    int32_t dist_bias;        // texel offset added before the shift (multiple of kBrick, > apron)
     int32_t nx, ny, nz;    // texels
     float sx, sy, sz;      // box coordinate -> texel coordinate (textureScale * N)
     float bx, by, bz;      // bboxSize          (VDBCloud.cpp:104)
@@ -144,17 +146,22 @@ CT_DEV float tex3_apron(const DevScene &sc, const uint2 *cells, f3 p)
     return filter_cell(c, fract_(x), fract_(y), fract_(z));
 }
 
-// The same fetch for the march, which also wants the free-space distance of the brick the
-// position falls in (both loads are issued together, so the distance costs no extra latency).
-CT_DEV float tex3_apron_dist(const DevScene &sc, const uint2 *cells, f3 p, uint32_t &dist_out)
+// The march's fetch, split from the filter so that all-zero cells can skip it; also returns the
+// free-space distance of the brick the position falls in (both loads are issued together, so the
+// distance costs no extra latency).
+CT_DEV void fetch_cell_dist(const DevScene &sc, const uint2 *cells, f3 p, uint2 &cell, float &wx, float &wy,
+                            float &wz, uint32_t &dist_out)
 {
     const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
     const int32_t ix = floor_to_int(x), iy = floor_to_int(y), iz = floor_to_int(z);
     const int32_t rel = __mul24(iz, sc.cell_sz) + __mul24(iy, sc.cell_sy) + ix;
-    const int32_t bx = (ix + sc.dist_bias) >> 3, by = (iy + sc.dist_bias) >> 3, bz = (iz + sc.dist_bias) >> 3;
-    const uint2 c = cells[sc.cell_origin + (int64_t)rel];
+    const int32_t bx = (ix + sc.dist_bias) >> kBrickShift, by = (iy + sc.dist_bias) >> kBrickShift,
+                  bz = (iz + sc.dist_bias) >> kBrickShift;
+    cell = cells[sc.cell_origin + (int64_t)rel];
     dist_out = sc.dist[__mul24(bz, sc.dist_sz) + __mul24(by, sc.dist_sy) + bx];
-    return filter_cell(c, fract_(x), fract_(y), fract_(z));
+    wx = fract_(x);
+    wy = fract_(y);
+    wz = fract_(z);
 }
 
 // tex3D with explicit clamp-to-edge, for the shadow-volume precompute which marches up to

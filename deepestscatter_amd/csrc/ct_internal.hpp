@@ -10,17 +10,26 @@ namespace ct {
 
 constexpr int kTile = 8;            // pixel tile edge: 8x8 = one wave of primary rays
 constexpr int kCounterCount = 6;    // paths, box_hits, density, inscatter, scatter, capped
+constexpr int kStatCount = 16;      // scheduler diagnostics (ct_debug_stats)
 
 // One progressive batch: subframes first .. first+S-1 of the handle's own tiles.
 struct BatchArgs {
     float4 *frames;            // [S][H][W] per-sample results (frameResultBuffer x S)
-    const uint32_t *tiles;     // tile ids owned by this shard, in traversal order
-    uint32_t n_tiles;
+    const float4 *primary;     // 2 float4 per pixel: cached primary ray (primary_rays_kernel)
+    const uint32_t *pixels;    // this shard's box-hitting pixels, 64 per group, 0xffffffff padded
+    // job list: job j renders subframes [begin, begin+count) of pixel group job_group[j];
+    // job_sub[j] = begin | count << 16.  Sorted most expensive group first, and expensive groups
+    // are cut into short jobs, so the long paths start early and spread over all waves while
+    // every wave still stays on one 64-pixel group at a time (cache locality).
+    const uint32_t *job_group;
+    const uint32_t *job_sub;
+    uint32_t *cost;            // per group: sum of path depths, feeds the next job list
+    uint32_t n_jobs;
     uint32_t first_subframe;   // 1-based subframeId of slice 0
     uint32_t S;
-    uint32_t total;            // n_tiles * S * 64 samples in the queue
     uint32_t *queue;           // global work counter, zero before launch
     unsigned long long *counters; // kCounterCount
+    unsigned long long *stats;    // kStatCount
 };
 
 struct LaunchShape {
@@ -39,12 +48,15 @@ hipError_t launch_build_cells(const uint8_t *texels, int nx, int ny, int nz, int
 hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
                              uint8_t *dist, uint8_t *scratch, hipStream_t stream);
 hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream);
+hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream);
+hipError_t launch_fill_frame(float4 *frame, uint32_t width, uint32_t height, uint32_t shard_index,
+                             uint32_t shard_count, hipStream_t stream);
 hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_t shard_index,
                                 uint32_t shard_count, hipStream_t stream);
-hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
-                                   uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
-                                   uint32_t shard_count, hipStream_t stream);
+hipError_t launch_accumulate_batch(const float4 *frames, const float4 *primary, float4 *mean, float4 *m2,
+                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
+                                   uint32_t shard_index, uint32_t shard_count, hipStream_t stream);
 hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure,
                            float *column_sums, float *avg, uchar4 *screen, hipStream_t stream);
 hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,

@@ -55,10 +55,9 @@ hipError_t launch_build_cells(const uint8_t *texels, int nx, int ny, int nz, int
 }
 
 // =============================================================================================
-// free-space distance field over 8^3-texel bricks (see DevScene::dist)
+// free-space distance field over kBrick^3-texel bricks (see DevScene::dist)
 // =============================================================================================
-constexpr int kBrick = 8;
-constexpr int kDistMax = 24;
+constexpr int kDistMax = 64;
 
 // dist = kDistMax for free bricks, 0 otherwise.  A brick is free when every texel a trilinear
 // footprint based inside it can read ([lo-1, hi+1]^3) is zero and its texel range lies in
@@ -214,6 +213,58 @@ CT_DEV f3 primary_direction(const DevScene &sc, uint32_t x, uint32_t y)
     return normalize3(add3(add3(scale3(U, dx), scale3(V, dy)), W));
 }
 
+// The primary ray of a pixel does not depend on the subframe (no jitter: cameraCommon.cuh:22),
+// so pinholeCamera + intersect + the closest-hit prologue (cloudRadianceMaterials.cu:11-17) are
+// evaluated once per camera pose: primary[2p] = (entry point in box coordinates, hit ? 1 : 0),
+// primary[2p+1] = (normalize(ray.direction), bits of the seed base x*4096+y).
+__global__ __launch_bounds__(256) void primary_rays_kernel(DevScene sc, float4 *__restrict__ primary)
+{
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
+    const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= sc.width || y >= sc.height) {
+        return;
+    }
+    const f3 eye = mk3(sc.ex, sc.ey, sc.ez);
+    const f3 d = primary_direction(sc, x, y);
+    float t_hit = 0;
+    const bool hit = intersect_box(sc, eye, d, t_hit);
+    f3 pos = add3(eye, scale3(d, t_hit));                       // :11
+    pos = add3(pos, scale3(mk3(sc.bx, sc.by, sc.bz), 0.5f));    // :12
+    const f3 dir = normalize3(d);                               // :17
+    const size_t p = (size_t)y * sc.width + x;
+    primary[2 * p] = make_float4(pos.x, pos.y, pos.z, hit ? 1.f : 0.f);
+    primary[2 * p + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(x * 4096u + y)); // :21
+}
+
+hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream)
+{
+    const dim3 grid((sc.width + 31) / 32, (sc.height + 7) / 8), block(256);
+    hipLaunchKernelGGL(primary_rays_kernel, grid, block, 0, stream, sc, primary);
+    return hipGetLastError();
+}
+
+// frameResultBuffer before a single-subframe render: (0,0,0,1) for this shard's pixels (misses
+// keep that value: empty miss program, progressive.cu:44-46), (0,0,0,0) for foreign pixels.
+__global__ void fill_frame_kernel(float4 *__restrict__ frame, uint32_t width, uint32_t height, uint32_t shard_index,
+                                  uint32_t shard_count)
+{
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
+    const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= width || y >= height) {
+        return;
+    }
+    const bool own = tile_owner(x / kTile, y / kTile, shard_count) == shard_index;
+    frame[(size_t)y * width + x] = make_float4(0.f, 0.f, 0.f, own ? 1.f : 0.f);
+}
+
+hipError_t launch_fill_frame(float4 *frame, uint32_t width, uint32_t height, uint32_t shard_index,
+                             uint32_t shard_count, hipStream_t stream)
+{
+    const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
+    hipLaunchKernelGGL(fill_frame_kernel, grid, block, 0, stream, frame, width, height, shard_index, shard_count);
+    return hipGetLastError();
+}
+
 // NEE: getInScattering, cloud.cuh:146-158.
 CT_DEV f3 in_scattering(const DevScene &sc, f3 pos, f3 dir, bool chopped)
 {
@@ -237,7 +288,6 @@ CT_DEV float inv_max_advance(const DevScene &sc, f3 stepv)
     return __builtin_amdgcn_rcpf(fmaxf(m, 1e-20f));
 }
 
-constexpr uint32_t kChunk = 512;    // samples a wave takes from the global queue at once
 constexpr uint32_t kRegenMin = 8;   // idle lanes that trigger a regeneration phase
 
 CT_DEV uint32_t lane_rank(uint64_t mask)
@@ -250,7 +300,10 @@ CT_DEV uint32_t lane_rank(uint64_t mask)
 // for, so lanes marching through empty space do not hold back lanes that collide every step
 // and finished paths are replaced immediately from a global sample queue.  Paths are
 // independent and seeded by (pixel, subframe) only, so the schedule cannot change a result.
-template <int MODE>
+//
+// The queue hands out jobs = (pixel group, subframe range); a group is 64 consecutive entries of
+// the list of this shard's box-hitting pixels (tile-Morton order).  See BatchArgs for the order.
+template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, BatchArgs ba)
 {
     __shared__ MieLds lds;
@@ -258,87 +311,88 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
 
     const uint32_t lane = threadIdx.x & 63u;
     f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), stepv = mk3(0, 0, 0), rad = mk3(0, 0, 0);
-    uint32_t seed = 0, depth = 0, out_idx = 0;
+    uint32_t seed = 0, depth = 0, out_idx = 0, group = 0;
     float xi = 0, T = 1;
     uint32_t dfree = 0;     // free-space distance of the brick `pos` is in (0 = unknown / none)
     float inv_maxd = 0;     // 1 / (largest per-axis texel advance of one step)
     int state = ST_IDLE;
 
-    // wave-uniform bookkeeping (lives in SGPRs)
-    uint32_t q_next = 0, q_end = 0;
+    // wave-uniform bookkeeping (lives in SGPRs): the current job and the samples left in it
+    uint32_t q_next = 0, q_end = 0, job_g = 0, job_s0 = 0;
     bool drained = false;
-    uint32_t c_paths = 0, c_hits = 0, c_dl = 0, c_il = 0, c_cap = 0;
+    uint32_t c_dl = 0, c_il = 0, c_cap = 0; // per-lane tallies
+    // scheduler diagnostics (STATS builds only), see ct_debug_stats
+    uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
+    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0;
 
-    const f3 eye = mk3(sc.ex, sc.ey, sc.ez);
+    const size_t plane = (size_t)sc.width * sc.height;
 
     for (;;) {
         // ---------------- regenerate ----------------
-        uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
-        uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
         if (n_idle >= kRegenMin && !(drained && q_next == q_end)) {
             if (q_next == q_end) {
-                uint32_t base = 0;
+                uint32_t j = 0;
                 if (lane == 0) {
-                    base = atomicAdd(ba.queue, kChunk);
+                    j = atomicAdd(ba.queue, 1u);
                 }
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= ba.total) {
+                j = __builtin_amdgcn_readfirstlane(j);
+                if (j >= ba.n_jobs) {
                     drained = true;
                 } else {
-                    q_next = base;
-                    q_end = min(base + kChunk, ba.total);
+                    const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
+                    job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
+                    job_s0 = sub & 0xffffu;
+                    q_next = 0;
+                    q_end = (sub >> 16) * 64u;
                 }
             }
             if (q_next != q_end) {
                 const uint32_t avail = q_end - q_next;
+                if (STATS) {
+                    st_regen += 1;
+                    st_regen_l += min(n_idle, avail);
+                }
                 const uint32_t rank = lane_rank(idle);
                 const bool take = (state == ST_IDLE) && rank < avail;
                 const uint32_t q = q_next + rank;
                 q_next += min(n_idle, avail);
                 if (take) {
-                    const uint32_t c = q >> 6, l = q & 63u;
-                    const uint32_t k = c / ba.S, s = c - k * ba.S;
-                    const uint32_t tile = ba.tiles[k];
-                    const uint32_t ty = tile / sc.tiles_x, tx = tile - ty * sc.tiles_x;
-                    const uint32_t x = tx * kTile + (l & 7u), y = ty * kTile + (l >> 3);
-                    if (x < sc.width && y < sc.height) {
-                        out_idx = (s * sc.height + y) * sc.width + x;
-                        const f3 d = primary_direction(sc, x, y);
-                        float t_hit;
-                        const bool hit = intersect_box(sc, eye, d, t_hit);
-                        c_paths += 1; // (summed per lane below; see flush)
-                        if (!hit) {
-                            ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f); // miss: progressive.cu:44-46
+                    const uint32_t s = job_s0 + (q >> 6), l = q & 63u;
+                    const uint32_t g = job_g;
+                    const uint32_t pixel = ba.pixels[g * 64u + l];
+                    if (pixel != 0xffffffffu) {
+                        const float4 p0 = ba.primary[2 * (size_t)pixel];
+                        const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
+                        out_idx = (uint32_t)(s * plane + pixel);
+                        group = g;
+                        pos = mk3(p0.x, p0.y, p0.z);
+                        dir = mk3(p1.x, p1.y, p1.z);
+                        seed = tea4(__float_as_uint(p1.w), ba.first_subframe + s); // :21
+                        rad = mk3(0, 0, 0);
+                        depth = 0;
+                        if (MODE == 1) {
+                            dir = new_direction(lds.cdf, lds.guide, seed, dir);  // :86
+                        }
+                        // first loop test + depth bump (:28-34); mode 2 has no loop (:134)
+                        bool go = in_box(sc, pos);
+                        if (MODE != 2 && go) {
+                            depth = 1;
+                            if (depth == sc.max_depth) {
+                                c_cap += 1;
+                                go = false;
+                            }
+                        }
+                        if (go) {
+                            xi = u24_to_float(lcg24(seed));
+                            T = 1;
+                            stepv = scale3(dir, sc.sample_step);
+                            inv_maxd = inv_max_advance(sc, stepv);
+                            dfree = 0;
+                            state = ST_MARCH;
                         } else {
-                            c_hits += 1;
-                            pos = add3(eye, scale3(d, t_hit));                       // :11
-                            pos = add3(pos, scale3(mk3(sc.bx, sc.by, sc.bz), 0.5f)); // :12
-                            dir = normalize3(d);                                     // :17
-                            seed = tea4(x * 4096u + y, ba.first_subframe + s);       // :21
-                            rad = mk3(0, 0, 0);
-                            depth = 0;
-                            if (MODE == 1) {
-                                dir = new_direction(lds.cdf, lds.guide, seed, dir);  // :86
-                            }
-                            // first loop test + depth bump (:28-34); mode 2 has no loop (:134)
-                            bool go = in_box(sc, pos);
-                            if (MODE != 2 && go) {
-                                depth = 1;
-                                if (depth == sc.max_depth) {
-                                    c_cap += 1;
-                                    go = false;
-                                }
-                            }
-                            if (go) {
-                                xi = u24_to_float(lcg24(seed));
-                                T = 1;
-                                stepv = scale3(dir, sc.sample_step);
-                                inv_maxd = inv_max_advance(sc, stepv);
-                                dfree = 0;
-                                state = ST_MARCH;
-                            } else {
-                                ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
-                            }
+                            ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
                         }
                     }
                 }
@@ -356,8 +410,13 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             continue; // everything idle: go regenerate (n_idle == 64 >= kRegenMin)
         }
 
+        bool finished = false;
         if (nb > nm) {
             // ---------------- scatter: NEE + new direction (cloudRadianceMaterials.cu:53-61) ----------------
+            if (STATS) {
+                st_scat += 1;
+                st_scat_l += nb;
+            }
             if (state == ST_BOUNCE) {
                 const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
                 rad = add3(rad, in_scattering(sc, pos, dir, chopped));
@@ -379,12 +438,15 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                     dfree = 0;
                     state = ST_MARCH;
                 } else {
-                    ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
-                    state = ST_IDLE;
+                    finished = true;
                 }
             }
         } else {
             // ---------------- march one step (getNextScatteringEvent, cloud.cuh:87-105) ----------------
+            if (STATS) {
+                st_march += 1;
+                st_march_l += nm;
+            }
             if (state == ST_MARCH) {
                 // Free-space skip: every brick within Chebyshev distance dfree-1 of the one `pos` is
                 // in is free, so the next n steps can neither collide (all 8 texels are 0, T *= 1)
@@ -397,34 +459,50 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                         pos = add3(pos, stepv);
                     }
                     c_dl += (uint32_t)n;
+                    if (STATS) {
+                        st_skip += (uint32_t)n;
+                    }
                 }
                 pos = add3(pos, stepv);
-                const float density = tex3_apron_dist(sc, sc.dcells, pos, dfree) * sc.density_multiplier;
+                uint2 cell;
+                float wx, wy, wz;
+                fetch_cell_dist(sc, sc.dcells, pos, cell, wx, wy, wz, dfree);
                 c_dl += 1;
-                const float extinction = density * sc.sample_step;
-                T *= expf_inrange(-extinction);
-                if (xi > T) {
-                    const float lg = ct_logf(xi / T);
-                    const float inv = 1.0f / density;
-                    pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
-                    if (in_box(sc, pos)) {
-                        state = ST_BOUNCE;
-                    } else {
-                        ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
-                        state = ST_IDLE;
+                if (STATS) {
+                    st_fetch += 1;
+                    st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
+                }
+                bool collided = false;
+                if ((cell.x | cell.y) != 0u) {
+                    // all-zero cells give density 0, exp(-0) = 1, T unchanged: nothing to evaluate
+                    const float density = filter_cell(cell, wx, wy, wz) * sc.density_multiplier;
+                    const float extinction = density * sc.sample_step;
+                    T *= expf_inrange(-extinction);
+                    if (xi > T) {
+                        collided = true;
+                        const float lg = ct_logf(xi / T);
+                        const float inv = 1.0f / density;
+                        pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
                     }
-                } else if (!in_box(sc, pos)) {
-                    ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
-                    state = ST_IDLE;
+                }
+                if (!in_box(sc, pos)) {
+                    finished = true;      // left the box, or scattered outside it (:49-52)
+                } else if (collided) {
+                    state = ST_BOUNCE;
                 }
             }
+        }
+        if (finished) {
+            ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+            atomicAdd(&ba.cost[group], depth);
+            state = ST_IDLE;
         }
     }
 
     // flush counters: per-lane tallies -> one atomic per counter per wave
-    uint32_t vals[5] = { c_paths, c_hits, c_dl, c_il, c_cap };
+    uint32_t vals[3] = { c_dl, c_il, c_cap };
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 3; i++) {
         uint32_t v = vals[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -432,13 +510,34 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         }
         vals[i] = v;
     }
+    if (STATS) {
+        uint32_t sv[3] = { st_fetch, st_zero, st_skip };
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            uint32_t v = sv[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                v += __shfl_xor(v, off);
+            }
+            sv[i] = v;
+        }
+        if (lane == 0) {
+            atomicAdd(&ba.stats[0], (unsigned long long)st_regen);
+            atomicAdd(&ba.stats[1], (unsigned long long)st_regen_l);
+            atomicAdd(&ba.stats[2], (unsigned long long)st_march);
+            atomicAdd(&ba.stats[3], (unsigned long long)st_march_l);
+            atomicAdd(&ba.stats[4], (unsigned long long)st_scat);
+            atomicAdd(&ba.stats[5], (unsigned long long)st_scat_l);
+            atomicAdd(&ba.stats[6], (unsigned long long)sv[0]);
+            atomicAdd(&ba.stats[7], (unsigned long long)sv[1]);
+            atomicAdd(&ba.stats[8], (unsigned long long)sv[2]);
+        }
+    }
     if (lane == 0) {
-        atomicAdd(&ba.counters[0], (unsigned long long)vals[0]);
-        atomicAdd(&ba.counters[1], (unsigned long long)vals[1]);
-        atomicAdd(&ba.counters[2], (unsigned long long)vals[2]);
-        atomicAdd(&ba.counters[3], (unsigned long long)vals[3]);
-        atomicAdd(&ba.counters[4], (unsigned long long)vals[3]); // scatter events == NEE lookups
-        atomicAdd(&ba.counters[5], (unsigned long long)vals[4]);
+        atomicAdd(&ba.counters[2], (unsigned long long)vals[0]);
+        atomicAdd(&ba.counters[3], (unsigned long long)vals[1]);
+        atomicAdd(&ba.counters[4], (unsigned long long)vals[1]); // scatter events == NEE lookups
+        atomicAdd(&ba.counters[5], (unsigned long long)vals[2]);
     }
 }
 
@@ -461,16 +560,19 @@ LaunchShape persistent_shape(int device)
 hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream)
 {
     const dim3 grid(shape.blocks), block(shape.threads);
-    switch (sc.mode) {
-    case 0:
-        hipLaunchKernelGGL(render_persistent_kernel<0>, grid, block, 0, stream, sc, ba);
-        break;
-    case 1:
-        hipLaunchKernelGGL(render_persistent_kernel<1>, grid, block, 0, stream, sc, ba);
-        break;
-    default:
-        hipLaunchKernelGGL(render_persistent_kernel<2>, grid, block, 0, stream, sc, ba);
-        break;
+    static const bool stats = getenv("CT_STATS") != nullptr; // diagnostics build of the same kernel
+    if (stats) {
+        switch (sc.mode) {
+        case 0: hipLaunchKernelGGL((render_persistent_kernel<0, true>), grid, block, 0, stream, sc, ba); break;
+        case 1: hipLaunchKernelGGL((render_persistent_kernel<1, true>), grid, block, 0, stream, sc, ba); break;
+        default: hipLaunchKernelGGL((render_persistent_kernel<2, true>), grid, block, 0, stream, sc, ba); break;
+        }
+    } else {
+        switch (sc.mode) {
+        case 0: hipLaunchKernelGGL((render_persistent_kernel<0, false>), grid, block, 0, stream, sc, ba); break;
+        case 1: hipLaunchKernelGGL((render_persistent_kernel<1, false>), grid, block, 0, stream, sc, ba); break;
+        default: hipLaunchKernelGGL((render_persistent_kernel<2, false>), grid, block, 0, stream, sc, ba); break;
+        }
     }
     return hipGetLastError();
 }
@@ -576,6 +678,7 @@ hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_
 // shards (RCCL) reproduces the single-GPU image bit for bit.
 // =============================================================================================
 __global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__restrict__ frames,
+                                                               const float4 *__restrict__ primary,
                                                                float4 *__restrict__ mean, float4 *__restrict__ m2,
                                                                uint32_t first_subframe, uint32_t S, uint32_t width,
                                                                uint32_t height, uint32_t shard_index,
@@ -591,9 +694,11 @@ __global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__r
     }
     const size_t pix = (size_t)y * width + x;
     const size_t plane = (size_t)width * height;
+    // pixels whose primary ray misses the box are never rendered: their sample is (0,0,0,1)
+    const bool rendered = primary == nullptr || primary[2 * pix].w != 0.f;
     float4 mu = mean[pix], var = m2[pix];
     for (uint32_t s = 0; s < S; s++) {
-        const float4 nr = frames[s * plane + pix];
+        const float4 nr = rendered ? frames[s * plane + pix] : make_float4(0.f, 0.f, 0.f, 1.f);
         const float w = 1.0f / (float)(first_subframe + s);
         float4 nm;
         nm.x = mu.x + (nr.x - mu.x) * w;
@@ -610,13 +715,13 @@ __global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__r
     m2[pix] = var;
 }
 
-hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
-                                   uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
-                                   uint32_t shard_count, hipStream_t stream)
+hipError_t launch_accumulate_batch(const float4 *frames, const float4 *primary, float4 *mean, float4 *m2,
+                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
+                                   uint32_t shard_index, uint32_t shard_count, hipStream_t stream)
 {
     const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
-    hipLaunchKernelGGL(accumulate_batch_kernel, grid, block, 0, stream, frames, mean, m2, first_subframe, S, width,
-                       height, shard_index, shard_count);
+    hipLaunchKernelGGL(accumulate_batch_kernel, grid, block, 0, stream, frames, primary, mean, m2, first_subframe, S,
+                       width, height, shard_index, shard_count);
     return hipGetLastError();
 }
 

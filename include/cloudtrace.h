@@ -223,6 +223,12 @@ CT_API int ct_counters(CtHandle h, CtCounters *out);
  * launches.  Any pointer may be NULL. */
 CT_API int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_ms_out, uint64_t *launches_out);
 
+/* Scheduler statistics of the estimator kernel since create/reset (implementation diagnostics, not
+ * part of the algorithm): out[0..15] = regen phases, regen lanes, march phases, march lanes,
+ * scatter phases, scatter lanes, fetched march steps, fetched steps whose 8 texels were all 0,
+ * skipped (replayed) march steps, skip-loop trips (wave level), rest reserved. */
+CT_API int ct_debug_stats(CtHandle h, uint64_t out[16]);
+
 /* Self-test hook: k(val) of the CDF inversion (cloud.cuh:162-180) for `count` consecutive 24-bit
  * random integers starting at first_u24, evaluated by the device code; cos(theta) = (2k+1)/65536-1. */
 CT_API int ct_debug_cdf_inversion(CtHandle h, uint32_t first_u24, uint32_t count, uint32_t *k_host_out);

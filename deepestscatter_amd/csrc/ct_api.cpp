@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -31,7 +32,7 @@ struct CtHandle_ {
 
     // device memory
     uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr;
-    uint2 *d_dcells = nullptr, *d_icells = nullptr;
+    uint8_t *d_dbricks = nullptr, *d_ibricks = nullptr;
     float *d_mie = nullptr, *d_chopped = nullptr, *d_cdf = nullptr;
     uint16_t *d_guide = nullptr;
     float4 *d_frame = nullptr, *d_mean = nullptr, *d_m2 = nullptr;
@@ -185,7 +186,7 @@ static void release(CtHandle h)
     if (h->stream) {
         hipStreamSynchronize(h->stream);
     }
-    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dcells, h->d_icells, h->d_mie, h->d_chopped, h->d_cdf,
+    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_primary, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
@@ -267,20 +268,24 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.tiles_x = (s->width + kTile - 1) / kTile;
     d.tiles_y = (s->height + kTile - 1) / kTile;
 
-    // apron: farthest texel a marching path can address (slack box + one step), see ct_device.hpp
-    const int apron = (int)ceilf((0.01f + s->sample_step) * fmaxf(fmaxf(d.sx, d.sy), d.sz) + 0.5f) + 1;
-    if (apron > 96) {
+    // apron: farthest texel a marching path can address: slack box + the steps it fetches
+    // speculatively in one scheduler visit (kSpec in ct_kernels.hip, 8 allowed for here)
+    const int apron = (int)ceilf((0.01f + 8.0f * s->sample_step) * fmaxf(fmaxf(d.sx, d.sy), d.sz) + 0.5f) + 1;
+    if (apron > 160) {
         return fail(h, CT_E_INVAL, "sample_step %g too coarse for a %u^3 volume", (double)s->sample_step,
                     (unsigned)maxs);
     }
-    const int64_t cx = nx + 2 * apron + 1, cy = ny + 2 * apron + 1, cz = nz + 2 * apron + 1;
-    if (cx * cy >= (1ll << 31) / cz) {
-        return fail(h, CT_E_INVAL, "volume too large for 32-bit cell indices");
+    // brick coordinates = (texel index + bias) / 4, bias a multiple of 4 covering the apron
+    const int bbias = ((apron + 3) / 4) * 4;
+    const int64_t bgx = ((int64_t)nx + 2 * bbias + 3) / 4 + 1, bgy = ((int64_t)ny + 2 * bbias + 3) / 4 + 1,
+                  bgz = ((int64_t)nz + 2 * bbias + 3) / 4 + 1;
+    if (bgx * bgy * bgz >= (1ll << 31) || bgx * bgy >= (1ll << 24)) {
+        return fail(h, CT_E_INVAL, "volume too large for 32-bit brick indices");
     }
-    d.cell_sy = (int32_t)cx;
-    d.cell_sz = (int32_t)(cx * cy);
-    d.cell_origin = (int64_t)apron * (cx * cy + cx + 1);
-    const size_t n_cells = (size_t)(cx * cy * cz);
+    d.brick_bias = bbias;
+    d.brick_gx = (int32_t)bgx;
+    d.brick_gxy = (int32_t)(bgx * bgy);
+    const size_t brick_bytes = (size_t)(bgx * bgy * bgz) * 128;
 
     // ---- Mie textures (Mie.cpp:8206-8297) + guide table
     std::vector<float> mie_tex, chopped_tex, cdf_tex;
@@ -307,12 +312,12 @@ static int create_impl(const CtScene *s, CtHandle h)
     // ---- density -> corner cells; shadow volume (VDBCloud::InitInScatter) -> corner cells
     HIPCHK(h, dmalloc(&h->d_density, texels));
     HIPCHK(h, dmalloc(&h->d_inscatter, texels));
-    HIPCHK(h, dmalloc(&h->d_dcells, n_cells));
-    HIPCHK(h, dmalloc(&h->d_icells, n_cells));
+    HIPCHK(h, dmalloc(&h->d_dbricks, brick_bytes));
+    HIPCHK(h, dmalloc(&h->d_ibricks, brick_bytes));
     HIPCHK(h, hipMemcpyAsync(h->d_density, s->density_host, texels, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, launch_build_cells(h->d_density, nx, ny, nz, apron, h->d_dcells, h->stream));
-    d.dcells = h->d_dcells;
-    d.icells = h->d_icells;
+    HIPCHK(h, launch_build_bricks(h->d_density, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_dbricks, h->stream));
+    d.dbricks = h->d_dbricks;
+    d.ibricks = h->d_ibricks;
     {
         // free-space distance field over kBrick^3 bricks (DevScene::dist)
         const int bias = ((apron + 1 + kBrick - 1) / kBrick) * kBrick;
@@ -328,7 +333,7 @@ static int create_impl(const CtScene *s, CtHandle h)
         d.dist_bias = bias;
     }
     HIPCHK(h, launch_inscatter(d, h->d_inscatter, h->stream));
-    HIPCHK(h, launch_build_cells(h->d_inscatter, nx, ny, nz, apron, h->d_icells, h->stream));
+    HIPCHK(h, launch_build_bricks(h->d_inscatter, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_ibricks, h->stream));
 
     // ---- Camera::init buffers (Camera.cpp:45-48) + reset (:77-86)
     const size_t pixels = (size_t)s->width * s->height;
@@ -385,7 +390,7 @@ extern "C" int ct_create(const CtScene *s, CtHandle *out)
         return fail(nullptr, CT_E_INVAL, "frame %ux%u out of range (seed packing x*4096+y needs H <= 4096)", s->width,
                     s->height);
     }
-    if (!(s->sample_step > 0.f) || !(s->sample_step <= 0.25f) || !(s->cloud_size_m > 0.f) ||
+    if (!(s->sample_step > 0.f) || !(s->sample_step <= 0.03125f) || !(s->cloud_size_m > 0.f) ||
         !(s->mean_free_path_m > 0.f) || s->max_depth < 2) {
         return fail(nullptr, CT_E_INVAL, "sample_step/cloud_size_m/mean_free_path_m/max_depth out of range");
     }

@@ -1,8 +1,8 @@
 // ct_device.hpp -- device-side building blocks of the gfx950 cloud path tracer.
 //
 // Everything here is written for CDNA4 (wave64, no texture filtering hardware): the
-// reference's texture fetches (cloud.cuh:58-68) become ONE 8-byte global load of a
-// pre-gathered 2x2x2 "corner cell" followed by an explicit float trilinear filter; the
+// reference's texture fetches (cloud.cuh:58-68) become two 8-byte loads from one 128-byte
+// "apron brick" followed by an explicit float trilinear filter; the
 // Mie tables live in LDS; the CDF inversion (cloud.cuh:160-180) is a guide-table search
 // that returns exactly what the reference's 16-step bisection returns.
 //
@@ -48,14 +48,18 @@ constexpr int kBrickShift = 2;
 
 // All uniforms of the path: the OptiX variable scopes of SURVEY section 8b, flattened.
 struct DevScene {
-    // corner-cell volumes: cell(ix,iy,iz) = the 8 texels {ix,ix+1}x{iy,iy+1}x{iz,iz+1},
-    // clamp-to-edge applied, byte order bit0=x bit1=y bit2=z; an apron of `apron` cells on
-    // every side makes the clamp implicit for every position the tracer can reach.
-    const uint2 *dcells;   // density
-    const uint2 *icells;   // inScatter (shadow volume)
-    int32_t cell_sy;       // cells per row
-    int32_t cell_sz;       // cells per slice
-    int64_t cell_origin;   // index of cell (0,0,0)
+    // Volumes live in HBM as "apron bricks": one 128-byte cache line per 4x4x4 texels holding the
+    // 5x5x5 texels [4b, 4b+4]^3 (clamp-to-edge applied) at byte lz*25 + ly*5 + lx.  The 2x2x2
+    // footprint of any trilinear lookup whose base texel lies in the brick is inside that one
+    // line and is read with two unaligned 8-byte loads (bytes o.. and o+25..).  Footprint is 2x the
+    // raw volume (a pre-gathered 8-byte corner per texel would be 8x and falls out of L2 and the
+    // Infinity Cache).  An apron of bricks around the texture makes clamp addressing implicit for
+    // every position the tracer can reach.
+    const uint8_t *dbricks;  // density
+    const uint8_t *ibricks;  // inScatter (shadow volume)
+    int32_t brick_bias;      // added to a texel index to make it non-negative (multiple of 4)
+    int32_t brick_gx;        // bricks per row
+    int32_t brick_gxy;       // bricks per slice
     // empty-space distance field over kBrick^3-texel bricks: dist[brick] = Chebyshev distance (in
     // bricks, capped) to the nearest brick that is not provably "free" (all texels a trilinear
     // footprint based in it can touch are zero AND every position in it passes isInBox).
@@ -127,6 +131,23 @@ CT_DEV float filter_cell(uint2 c, float wx, float wy, float wz)
     return fmaf(wz, c1 - c0, c0) * (1.0f / 255.0f);
 }
 
+// The 8 texels of the trilinear footprint based at texel (ix,iy,iz), packed as
+// .x = t000 | t100<<8 | t010<<16 | t110<<24, .y = the same for z+1.
+CT_DEV uint2 load_footprint(const DevScene &sc, const uint8_t *bricks, int32_t ix, int32_t iy, int32_t iz)
+{
+    const uint32_t x = (uint32_t)(ix + sc.brick_bias), y = (uint32_t)(iy + sc.brick_bias), z = (uint32_t)(iz + sc.brick_bias);
+    const uint32_t brick = __umul24(z >> 2, (uint32_t)sc.brick_gxy) + __umul24(y >> 2, (uint32_t)sc.brick_gx) + (x >> 2);
+    const uint32_t local = __umul24(z & 3u, 25u) + __umul24(y & 3u, 5u) + (x & 3u);
+    const uint8_t *p = bricks + (((size_t)brick << 7) | local);
+    uint2 a, c;
+    __builtin_memcpy(&a, p, 8);       // bytes o+0, o+1 (y) and o+5, o+6 (y+1)
+    __builtin_memcpy(&c, p + 25, 8);  // the same one z-slice up
+    uint2 r;
+    r.x = __builtin_amdgcn_perm(a.y, a.x, 0x06050100u);
+    r.y = __builtin_amdgcn_perm(c.y, c.x, 0x06050100u);
+    return r;
+}
+
 // (int)floorf(x) in one instruction (v_cvt_flr_i32_f32); identical for every in-range x.
 CT_DEV int32_t floor_to_int(float x)
 {
@@ -137,36 +158,40 @@ CT_DEV int32_t floor_to_int(float x)
 
 // tex3D for positions the tracer can reach (inside the slack box +- one step): no clamp, the
 // apron supplies clamp-to-edge.
-CT_DEV float tex3_apron(const DevScene &sc, const uint2 *cells, f3 p)
+CT_DEV float tex3_apron(const DevScene &sc, const uint8_t *bricks, f3 p)
 {
     const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
     const int32_t ix = floor_to_int(x), iy = floor_to_int(y), iz = floor_to_int(z);
-    const int32_t rel = __mul24(iz, sc.cell_sz) + __mul24(iy, sc.cell_sy) + ix;
-    const uint2 c = cells[sc.cell_origin + (int64_t)rel];
+    const uint2 c = load_footprint(sc, bricks, ix, iy, iz);
     return filter_cell(c, fract_(x), fract_(y), fract_(z));
 }
 
-// The march's fetch, split from the filter so that all-zero cells can skip it; also returns the
-// free-space distance of the brick the position falls in (both loads are issued together, so the
-// distance costs no extra latency).
-CT_DEV void fetch_cell_dist(const DevScene &sc, const uint2 *cells, f3 p, uint2 &cell, float &wx, float &wy,
-                            float &wz, uint32_t &dist_out)
+// The march splits the texture fetch in three so that several loads can be in flight and all-zero
+// cells can skip the filter: the cell load, the free-space distance of the brick a position is in,
+// and the filter at a position.
+CT_DEV uint2 fetch_cell(const DevScene &sc, const uint8_t *bricks, f3 p)
 {
     const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
-    const int32_t ix = floor_to_int(x), iy = floor_to_int(y), iz = floor_to_int(z);
-    const int32_t rel = __mul24(iz, sc.cell_sz) + __mul24(iy, sc.cell_sy) + ix;
-    const int32_t bx = (ix + sc.dist_bias) >> kBrickShift, by = (iy + sc.dist_bias) >> kBrickShift,
-                  bz = (iz + sc.dist_bias) >> kBrickShift;
-    cell = cells[sc.cell_origin + (int64_t)rel];
-    dist_out = sc.dist[__mul24(bz, sc.dist_sz) + __mul24(by, sc.dist_sy) + bx];
-    wx = fract_(x);
-    wy = fract_(y);
-    wz = fract_(z);
+    return load_footprint(sc, bricks, floor_to_int(x), floor_to_int(y), floor_to_int(z));
+}
+
+CT_DEV uint32_t fetch_dist(const DevScene &sc, f3 p)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    const int32_t bx = (floor_to_int(x) + sc.dist_bias) >> kBrickShift, by = (floor_to_int(y) + sc.dist_bias) >> kBrickShift,
+                  bz = (floor_to_int(z) + sc.dist_bias) >> kBrickShift;
+    return sc.dist[__mul24(bz, sc.dist_sz) + __mul24(by, sc.dist_sy) + bx];
+}
+
+CT_DEV float filter_at(const DevScene &sc, uint2 cell, f3 p)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    return filter_cell(cell, fract_(x), fract_(y), fract_(z));
 }
 
 // tex3D with explicit clamp-to-edge, for the shadow-volume precompute which marches up to
 // one box length away from the box (inScatter.cu:55-59 has no box test).
-CT_DEV float tex3_clamped(const DevScene &sc, const uint2 *cells, f3 p)
+CT_DEV float tex3_clamped(const DevScene &sc, const uint8_t *bricks, f3 p)
 {
     const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
     const float flx = floorf(x), fly = floorf(y), flz = floorf(z);
@@ -174,8 +199,7 @@ CT_DEV float tex3_clamped(const DevScene &sc, const uint2 *cells, f3 p)
     const int32_t ix = (int32_t)fminf(fmaxf(flx, -1.0f), (float)(sc.nx - 1));
     const int32_t iy = (int32_t)fminf(fmaxf(fly, -1.0f), (float)(sc.ny - 1));
     const int32_t iz = (int32_t)fminf(fmaxf(flz, -1.0f), (float)(sc.nz - 1));
-    const int64_t idx = sc.cell_origin + (int64_t)(iz * sc.cell_sz + iy * sc.cell_sy + ix);
-    const uint2 c = cells[idx];
+    const uint2 c = load_footprint(sc, bricks, ix, iy, iz);
     return filter_cell(c, fract_(x), fract_(y), fract_(z));
 }
 

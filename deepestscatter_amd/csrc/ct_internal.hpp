@@ -43,8 +43,8 @@ __host__ __device__ inline uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_
     return shard_count <= 1 ? 0u : (tx + 3u * ty) % shard_count;
 }
 
-hipError_t launch_build_cells(const uint8_t *texels, int nx, int ny, int nz, int apron, uint2 *cells,
-                              hipStream_t stream);
+hipError_t launch_build_bricks(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
+                               uint8_t *bricks, hipStream_t stream);
 hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
                              uint8_t *dist, uint8_t *scratch, hipStream_t stream);
 hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream);

@@ -7,7 +7,7 @@
 //                              cross-check only)
 //   accumulate_batch_kernel    updateFrameResult (progressive.cu:17-27) over S subframes in order
 //   inscatter_kernel           inScatter.cu:40-66
-//   build_cells_kernel         uint8 volume -> 8-byte corner cells (replaces the texture unit)
+//   build_bricks_kernel        uint8 volume -> 128-byte apron bricks (replaces the texture unit)
 //   reinhard_*                 reinhard.cu:26-84
 //   converged_kernel           Camera::isConverged (Camera.cpp:232-268)
 //
@@ -21,36 +21,36 @@ namespace ct {
 // =============================================================================================
 // corner cells
 // =============================================================================================
-__global__ void build_cells_kernel(const uint8_t *__restrict__ t, int nx, int ny, int nz, int apron,
-                                   uint2 *__restrict__ cells, int cx, int cy, int cz)
+// One thread per byte of the brick array: brick b = (bz*gy + by)*gx + bx holds the texels
+// [4b - bias, 4b - bias + 4]^3 with clamp-to-edge at byte lz*25 + ly*5 + lx; bytes 125..127 pad.
+__global__ void build_bricks_kernel(const uint8_t *__restrict__ t, int nx, int ny, int nz, int bias,
+                                    uint8_t *__restrict__ bricks, int gx, int gy, int gz)
 {
-    const int64_t total = (int64_t)cx * cy * cz;
+    const int64_t total = (int64_t)gx * gy * gz * 128;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % cx) - apron;
-        const int y = (int)((i / cx) % cy) - apron;
-        const int z = (int)(i / ((int64_t)cx * cy)) - apron;
-        const int x0 = min(max(x, 0), nx - 1), x1 = min(max(x + 1, 0), nx - 1);
-        const int y0 = min(max(y, 0), ny - 1), y1 = min(max(y + 1, 0), ny - 1);
-        const int z0 = min(max(z, 0), nz - 1), z1 = min(max(z + 1, 0), nz - 1);
-        const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
-        uint2 c;
-        c.x = (uint32_t)t[z0 * sz + y0 * sy + x0] | ((uint32_t)t[z0 * sz + y0 * sy + x1] << 8) |
-              ((uint32_t)t[z0 * sz + y1 * sy + x0] << 16) | ((uint32_t)t[z0 * sz + y1 * sy + x1] << 24);
-        c.y = (uint32_t)t[z1 * sz + y0 * sy + x0] | ((uint32_t)t[z1 * sz + y0 * sy + x1] << 8) |
-              ((uint32_t)t[z1 * sz + y1 * sy + x0] << 16) | ((uint32_t)t[z1 * sz + y1 * sy + x1] << 24);
-        cells[i] = c;
+        const int64_t b = i >> 7;
+        const int o = (int)(i & 127);
+        uint8_t v = 0;
+        if (o < 125) {
+            const int lx = o % 5, ly = (o / 5) % 5, lz = o / 25;
+            const int x = (int)(b % gx) * 4 + lx - bias;
+            const int y = (int)((b / gx) % gy) * 4 + ly - bias;
+            const int z = (int)(b / ((int64_t)gx * gy)) * 4 + lz - bias;
+            const int xc = min(max(x, 0), nx - 1), yc = min(max(y, 0), ny - 1), zc = min(max(z, 0), nz - 1);
+            v = t[((size_t)zc * ny + yc) * nx + xc];
+        }
+        bricks[i] = v;
     }
 }
 
-hipError_t launch_build_cells(const uint8_t *texels, int nx, int ny, int nz, int apron, uint2 *cells,
-                              hipStream_t stream)
+hipError_t launch_build_bricks(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
+                               uint8_t *bricks, hipStream_t stream)
 {
-    const int cx = nx + 2 * apron + 1, cy = ny + 2 * apron + 1, cz = nz + 2 * apron + 1;
-    const int64_t total = (int64_t)cx * cy * cz;
+    const int64_t total = (int64_t)gx * gy * gz * 128;
     const int threads = 256;
-    const int blocks = (int)((total + threads - 1) / threads < 16384 ? (total + threads - 1) / threads : 16384);
-    hipLaunchKernelGGL(build_cells_kernel, dim3(blocks), dim3(threads), 0, stream, texels, nx, ny, nz, apron, cells,
-                       cx, cy, cz);
+    const int blocks = (int)((total + threads - 1) / threads < 65536 ? (total + threads - 1) / threads : 65536);
+    hipLaunchKernelGGL(build_bricks_kernel, dim3(blocks), dim3(threads), 0, stream, texels, nx, ny, nz, bias, bricks,
+                       gx, gy, gz);
     return hipGetLastError();
 }
 
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void inscatter_kernel(DevScene sc, uint8_t *__
     const int step_count = (int)(1 / sc.sample_step);
     float transmittance = 1;
     for (int s = 0; s < step_count; s++) {
-        const float density = tex3_clamped(sc, sc.dcells, p) * sc.density_multiplier;
+        const float density = tex3_clamped(sc, sc.dbricks, p) * sc.density_multiplier;
         const float extinction = density * sc.sample_step;
         transmittance *= ct_expf(-extinction);
         p = add3(p, step_to_light);
@@ -272,7 +272,7 @@ CT_DEV f3 in_scattering(const DevScene &sc, f3 pos, f3 dir, bool chopped)
     const float u = (cos_light + 1) / 2;
     const float *table = chopped ? sc.chopped : sc.mie;
     const float phase = tex1(table, u);
-    const float ins = tex3_apron(sc, sc.icells, pos);
+    const float ins = tex3_apron(sc, sc.ibricks, pos);
     f3 l = scale3(mk3(sc.lr, sc.lg, sc.lb), ins);
     l = scale3(l, phase);
     return scale3(l, sc.sun_ratio);
@@ -289,6 +289,7 @@ CT_DEV float inv_max_advance(const DevScene &sc, f3 stepv)
 }
 
 constexpr uint32_t kRegenMin = 8;   // idle lanes that trigger a regeneration phase
+constexpr int kSpec = 1;            // march steps fetched speculatively per scheduler visit
 
 CT_DEV uint32_t lane_rank(uint64_t mask)
 {
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 }
             }
         } else {
-            // ---------------- march one step (getNextScatteringEvent, cloud.cuh:87-105) ----------------
+            // ---------------- march (getNextScatteringEvent, cloud.cuh:87-105) ----------------
             if (STATS) {
                 st_march += 1;
                 st_march_l += nm;
@@ -463,32 +464,53 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                         st_skip += (uint32_t)n;
                     }
                 }
-                pos = add3(pos, stepv);
-                uint2 cell;
-                float wx, wy, wz;
-                fetch_cell_dist(sc, sc.dcells, pos, cell, wx, wy, wz, dfree);
-                c_dl += 1;
-                if (STATS) {
-                    st_fetch += 1;
-                    st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
+                // Speculative fetch of the next kSpec cells along the ray: the positions do not
+                // depend on the fetched data, so all loads go out together.  Consecutive steps
+                // mostly fall into the same 128-byte line, which is then fetched once per burst
+                // instead of once per step, and the dependent-latency chain is kSpec times shorter.
+                // Steps after a collision / exit are simply not consumed.
+                uint2 cell[kSpec];
+                {
+                    f3 p = pos;
+#pragma unroll
+                    for (int k = 0; k < kSpec; k++) {
+                        p = add3(p, stepv);
+                        cell[k] = fetch_cell(sc, sc.dbricks, p);
+                    }
+                    dfree = fetch_dist(sc, p);
                 }
-                bool collided = false;
-                if ((cell.x | cell.y) != 0u) {
-                    // all-zero cells give density 0, exp(-0) = 1, T unchanged: nothing to evaluate
-                    const float density = filter_cell(cell, wx, wy, wz) * sc.density_multiplier;
-                    const float extinction = density * sc.sample_step;
-                    T *= expf_inrange(-extinction);
-                    if (xi > T) {
-                        collided = true;
-                        const float lg = ct_logf(xi / T);
-                        const float inv = 1.0f / density;
-                        pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
+#pragma unroll
+                for (int k = 0; k < kSpec; k++) {
+                    if (state == ST_MARCH) {
+                        pos = add3(pos, stepv);
+                        c_dl += 1;
+                        if (STATS) {
+                            st_fetch += 1;
+                            st_zero += ((cell[k].x | cell[k].y) == 0u) ? 1u : 0u;
+                        }
+                        bool collided = false;
+                        if ((cell[k].x | cell[k].y) != 0u) {
+                            // all-zero cells give density 0, exp(-0) = 1, T unchanged: nothing to evaluate
+                            const float density = filter_at(sc, cell[k], pos) * sc.density_multiplier;
+                            const float extinction = density * sc.sample_step;
+                            T *= expf_inrange(-extinction);
+                            if (xi > T) {
+                                collided = true;
+                                const float lg = ct_logf(xi / T);
+                                const float inv = 1.0f / density;
+                                pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
+                            }
+                        }
+                        if (!in_box(sc, pos)) {
+                            finished = true;      // left the box, or scattered outside it (:49-52)
+                            state = ST_IDLE;
+                        } else if (collided) {
+                            state = ST_BOUNCE;
+                        }
                     }
                 }
-                if (!in_box(sc, pos)) {
-                    finished = true;      // left the box, or scattered outside it (:49-52)
-                } else if (collided) {
-                    state = ST_BOUNCE;
+                if (state != ST_MARCH) {
+                    dfree = 0; // the distance was fetched for a position this path never reached
                 }
             }
         }
@@ -630,7 +652,7 @@ __global__ __launch_bounds__(256) void render_simple_kernel(DevScene sc, BatchAr
             bool scattered = false;
             while (in_box(sc, pos)) {
                 pos = add3(pos, stepv);
-                const float density = tex3_apron(sc, sc.dcells, pos) * sc.density_multiplier;
+                const float density = tex3_apron(sc, sc.dbricks, pos) * sc.density_multiplier;
                 c_dl++;
                 const float extinction = density * sc.sample_step;
                 T *= ct_expf(-extinction);

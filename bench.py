@@ -7,9 +7,11 @@ reduce of the accumulated radiance buffer).
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one progressive batch of --spp-per-step subframes of the whole frame: estimator
-kernel + Welford accumulate kernel, plus (N>1) the reduce of the W*H float4 radiance buffer to
-rank 0.  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
+A "step" = one progressive batch of --spp-per-step (default 64) subframes of the whole frame:
+estimator kernel + Welford accumulate kernel, plus (N>1) the reduce of the W*H float4 radiance
+buffer to rank 0.  (The reference updates its display every 10 subframes and saves every 40,
+Camera.cpp:189,211; a launch cannot be shorter than its longest 2000-bounce path, ~12 ms, so
+batches of 64 keep that tail below 15 % of a step.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
 before the timed region and resident in HBM).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -37,7 +39,8 @@ def parse_args():
     ap.add_argument("--volume", type=int, default=512, help="density texture edge (texels)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=64,
+                    help="subframes per progressive batch (one estimator launch + one accumulate launch)")
     ap.add_argument("--mode", type=int, default=0, help="0 totalRadiance (Mie multi-scatter + NEE)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,19 +106,15 @@ def main():
     t_setup = time.perf_counter()
     tex = ds.make_procedural_cloud(args.volume)
     flags = _lib.CT_FLAG_SIMPLE_KERNEL if args.simple_kernel else 0
-    tr = ds.CloudTracer(tex, width=W, height=H, mode=args.mode, device=local_rank, shard_index=rank,
-                        shard_count=world, flags=flags)
+    from deepestscatter_amd.distributed import ShardedTracer
+    st = ShardedTracer(tex, ds.SceneParams(width=W, height=H, mode=args.mode, flags=flags), rank, world, local_rank)
+    tr = st.tracer
     setup_s = time.perf_counter() - t_setup
 
-    merged = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    nbytes = merged.numel() * 4
-
     def step(first):
-        tr.render_accumulate(first, S)
-        if world > 1:
-            # frame reduce: tiles are disjoint, so SUM merges the per-GPU radiance buffers exactly
-            tr.copy_to_device(_lib.CT_BUF_MEAN, merged.data_ptr(), nbytes)
-            dist.reduce(merged, dst=0, op=dist.ReduceOp.SUM)
+        # estimator + accumulate on this rank's tiles, then (N>1) the RCCL SUM-reduce of the W*H float4
+        # radiance buffer to rank 0: tiles are disjoint, so the sum is an exact merge
+        st.step(first, S)
 
     def fence():
         if world > 1:

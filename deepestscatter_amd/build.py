@@ -43,13 +43,31 @@ def needs_build() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc(), *FLAGS, "-o", str(LIB), *[str(CSRC / s) for s in SOURCES]]
+HOST = PKG / "host"
+CLI = HOST / "cloudtrace"
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> Path:
+    """The C++ host mirror of the reference's scene classes + headless CLI (g++, links the C ABI)."""
+    srcs = [HOST / "main.cpp", HOST / "Cameras.h", HOST / "Scene.h", HOST / "SceneDescription.h",
+            ROOT / "include" / "cloudtrace.h"]
+    if not force and CLI.exists() and LIB.exists() and all(s.stat().st_mtime <= CLI.stat().st_mtime for s in srcs + [LIB]):
+        return CLI
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-o", str(CLI), str(HOST / "main.cpp"), f"-L{PKG}", "-lcloudtrace",
+           "-Wl,-rpath,$ORIGIN/.."]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=str(CSRC))
+    subprocess.run(cmd, check=True)
+    return CLI
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if force or needs_build():
+        cmd = [hipcc(), *FLAGS, "-o", str(LIB), *[str(CSRC / s) for s in SOURCES]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=str(CSRC))
+    build_cli(force=force, verbose=verbose)
     return LIB
 
 

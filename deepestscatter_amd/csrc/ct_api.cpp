@@ -246,8 +246,10 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.sz = (maxs / fz) * fz;
     d.density_multiplier = s->cloud_size_m / s->mean_free_path_m;
     d.sample_step = s->sample_step;
-    float l[3];
-    v3_normalize_twice(s->light_direction, l);
+    float l[3] = { s->light_direction[0], s->light_direction[1], s->light_direction[2] };
+    if (!(s->flags & CT_FLAG_LIGHT_NORMALIZED)) {
+        v3_normalize_twice(s->light_direction, l);
+    }
     d.nlx = -l[0];
     d.nly = -l[1];
     d.nlz = -l[2];

@@ -1,0 +1,215 @@
+// Cameras.h -- ARenderer plug-in seam + Camera, mirroring src/Scene/Cameras/{ARenderer.h,
+// PathTracingRenderer.{h,cpp},Camera.{h,cpp}} on top of the libcloudtrace C ABI.
+#pragma once
+
+#include <algorithm>
+#include <cfloat>
+#include <filesystem>
+
+#include "Scene.h"
+
+namespace DeepestScatter
+{
+    // What the reference passes around as optix::Program camera / optix::Buffer frameResultBuffer.
+    struct CameraProgram
+    {
+        float3 eye{}, U{}, V{}, W{};
+        bool valid = false;
+    };
+
+    class ARenderer                                                              // ARenderer.h:6-16
+    {
+    public:
+        ARenderer() = default;
+        virtual ~ARenderer() = default;
+
+        virtual CameraProgram* getCamera() = 0;
+        virtual void init() = 0;
+        virtual void render(float* frameResultBuffer /* device pointer, W*H*4 floats, or nullptr */) = 0;
+    };
+
+    class PathTracingRenderer : public ARenderer                                // PathTracingRenderer.h:8-31
+    {
+    public:
+        explicit PathTracingRenderer(std::shared_ptr<Context> context) : context(std::move(context)) {}
+        ~PathTracingRenderer() override = default;
+
+        CameraProgram* getCamera() override { return &camera; }
+
+        void init() override                                                     // PathTracingRenderer.cpp:14-19
+        {
+            // all scene items have published their variables by now (installApp order, installers.cpp:32-35)
+            CtScene& s = context->scene;
+            s.density_host = context->density.data();
+            s.mie_host = context->mie.data();
+            s.chopped_mie_host = context->choppedMie.data();
+            s.mie_count = (uint32_t)context->mie.size();
+            s.estimator = CT_EST_MARCH;
+            context->destroy();
+            Context::check(ct_create(&s, &context->handle), nullptr, "ct_create");
+            context->density.clear();
+            context->density.shrink_to_fit();
+        }
+
+        void render(float* frameResultBuffer) override                           // PathTracingRenderer.cpp:21-31
+        {
+            if (camera.valid)
+            {
+                Context::check(ct_set_camera(context->handle, camera.eye.data(), camera.U.data(), camera.V.data(), camera.W.data()),
+                               context->handle, "ct_set_camera");
+                camera.valid = false;
+            }
+            Context::check(ct_render_subframe(context->handle, subframeId, frameResultBuffer), context->handle, "ct_render_subframe");
+        }
+
+        uint32_t subframeId = 0;        // context["subframeId"], set by Camera::render (Camera.cpp:191-192)
+        inline static const std::string NAME = "PT";
+
+    private:
+        std::shared_ptr<Context> context;
+        CameraProgram camera;
+    };
+
+    class Camera : public SceneItem                                              // Camera.h:16-103
+    {
+    public:
+        struct Settings
+        {
+            Settings(uint32_t width, uint32_t height, std::filesystem::path outputFile)
+                : width(width), height(height), outputFile(std::move(outputFile)) {}
+            uint32_t width, height;
+            std::filesystem::path outputFile;
+        };
+
+        Camera(std::shared_ptr<Settings> settings, std::shared_ptr<Context> context, std::shared_ptr<ARenderer> renderer)
+            : width(settings->width), height(settings->height), outputFile(settings->outputFile),
+              context(std::move(context)), renderer(std::move(renderer))
+        {
+            this->context->scene.width = width;
+            this->context->scene.height = height;
+        }
+
+        void init() override                                                     // Camera.cpp:22-66
+        {
+            renderer->init();
+            cameraEye = { 2.5f, -0.4f, 0.f };                                    // :37-39
+            cameraLookat = { 0.f, 0.f, 0.f };
+            cameraUp = { 0.f, 1.f, 0.f };
+            updatePosition();
+            reset();
+        }
+
+        void update() override { if (!isCompleted()) { updatePosition(); render(); } }   // :68-75
+
+        void reset() override                                                    // :77-86
+        {
+            subframeId = 0;
+            Context::check(ct_reset(context->handle), context->handle, "ct_reset");
+        }
+
+        bool isCompleted() override { return completed; }
+
+        void setEye(const float3& eye) { cameraEye = eye; updatePosition(); reset(); }    // stands in for rotate(), :93-98
+        void increaseExposure() { exposure *= 1.2f; }
+        void decreaseExposure() { exposure /= 1.2f; }
+
+        // How many subframes one render() call adds (10 in the reference, Camera.cpp:189) and when to stop
+        // regardless of convergence (the reference runs until converged).
+        uint32_t subframesPerUpdate = 10;
+        uint32_t maxSubframes = 0;      // 0 = until isConverged()
+        bool fused = true;              // one ct_render_accumulate per update instead of 2 launches per subframe
+        bool completed = true;          // Camera.h:55
+
+        uint32_t getSubframeId() const { return subframeId; }
+        const std::vector<uint8_t>& getScreen() const { return screen; }
+
+        void saveToDisk() const                                                  // :149-175 (EXR R,G,B FLOAT there)
+        {
+            // OpenEXR is not available on the target image: write a PFM (RGB float32, bottom row first,
+            // which is exactly the buffer's own row order: row 0 = bottom).
+            std::vector<float> mean((size_t)width * height * 4);
+            Context::check(ct_download(context->handle, CT_BUF_MEAN, mean.data(), mean.size() * sizeof(float)), context->handle, "ct_download");
+            std::cout << mean[((size_t)width * height / 2 + width / 2) * 4] << std::endl;   // :163
+            std::ofstream f(outputFile, std::ios::binary);
+            f << "PF\n" << width << " " << height << "\n-1.0\n";
+            for (size_t i = 0; i < (size_t)width * height; i++) f.write(reinterpret_cast<const char*>(&mean[4 * i]), 3 * sizeof(float));
+        }
+
+    private:
+        void updatePosition()                                                    // :100-134 (arcball path is UI-only)
+        {
+            const float hfov = 30.0f;
+            const float aspectRatio = static_cast<float>(width) / static_cast<float>(height);
+            CameraProgram* camera = renderer->getCamera();
+            if (camera != nullptr)
+            {
+                ct_calculate_camera_variables(cameraEye.data(), cameraLookat.data(), cameraUp.data(), hfov, aspectRatio,
+                                              camera->U.data(), camera->V.data(), camera->W.data());
+                camera->eye = cameraEye;
+                camera->valid = true;
+            }
+        }
+
+        void render()                                                            // :177-230
+        {
+            if (!isConverged() && !(maxSubframes && subframeId >= maxSubframes))
+            {
+                uint32_t count = subframesPerUpdate;
+                if (maxSubframes) count = std::min(count, maxSubframes - subframeId);
+                auto* pt = dynamic_cast<PathTracingRenderer*>(renderer.get());
+                if (fused && pt != nullptr)
+                {
+                    CameraProgram* camera = renderer->getCamera();
+                    if (camera->valid)
+                    {
+                        Context::check(ct_set_camera(context->handle, camera->eye.data(), camera->U.data(), camera->V.data(), camera->W.data()),
+                                       context->handle, "ct_set_camera");
+                        camera->valid = false;
+                    }
+                    Context::check(ct_render_accumulate(context->handle, subframeId + 1, count), context->handle, "ct_render_accumulate");
+                    subframeId += count;
+                    std::cout << "rendering subframe " << subframeId << std::endl;
+                }
+                else
+                {
+                    for (uint32_t i = 0; i < count; i++)
+                    {
+                        subframeId++;
+                        if (pt) pt->subframeId = subframeId;                      // context["subframeId"]->setUint, :192
+                        std::cout << "rendering subframe " << subframeId << std::endl;
+                        renderer->render(nullptr);                                // :195
+                        Context::check(ct_accumulate(context->handle, subframeId, nullptr), context->handle, "ct_accumulate");   // :197-199
+                    }
+                }
+                screen.resize((size_t)width * height * 4);
+                Context::check(ct_tonemap(context->handle, exposure, screen.data(), nullptr), context->handle, "ct_tonemap");   // :202-210
+                if (subframeId % 40 == 0) saveToDisk();                           // :211-214
+            }
+            else
+            {
+                completed = true;
+                std::cout << "rendering subframe " << subframeId << std::endl;
+                saveToDisk();
+            }
+        }
+
+        bool isConverged()                                                       // :232-268 (evaluated on the device)
+        {
+            if (subframeId < 100) return false;
+            int32_t converged = 0;
+            uint64_t left = 0;
+            Context::check(ct_is_converged(context->handle, &converged, &left), context->handle, "ct_is_converged");
+            std::cout << "Converged: " << (uint64_t)width * height - left << "/" << (uint64_t)width * height << " --- " << left << "left" << std::endl;
+            return converged != 0;
+        }
+
+        uint32_t width, height;
+        std::filesystem::path outputFile;
+        std::shared_ptr<Context> context;
+        std::shared_ptr<ARenderer> renderer;
+        uint32_t subframeId = 0;
+        float3 cameraUp{}, cameraLookat{}, cameraEye{};
+        float exposure = 0.4f;                                                   // Camera.h:90
+        std::vector<uint8_t> screen;
+    };
+}

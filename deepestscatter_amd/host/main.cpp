@@ -1,0 +1,139 @@
+// cloudtrace -- headless equivalent of the reference's entry point for the path-traced image:
+// main (src/main.cpp:26-77) -> Tasks::renderCloud (ExecutionLoop/Tasks.cpp:49-112): two tasks, light
+// "Side" then "Back", 512x256, 7000 m, output <cloud>.<Light>.PT.pfm.  The GLUT loop
+// (GuiExecutionLoop.cpp:85-128) becomes a plain while(!scene->isCompleted()) scene->update().
+//
+//   cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light Side|Back|Front]
+//              [--size-m 7000] [--out DIR] [--data DIR] [--unfused]
+//   <cloud> = procedural:<N>[:<seed>] | file.f32grid
+#include <chrono>
+#include <cstring>
+#include <functional>
+#include <queue>
+
+#include "Cameras.h"
+
+using namespace DeepestScatter;
+
+namespace
+{
+    enum class LightDirection { Front, Side, Back };
+
+    float3 getLightDirection(LightDirection direction)                            // Tasks.cpp:52-65
+    {
+        switch (direction)
+        {
+        case LightDirection::Front: return { -0.586f, -0.766f, -0.271f };
+        case LightDirection::Side: return { -0.03f, -0.25f, 0.8f };
+        case LightDirection::Back: return { 0.586f, -0.766f, -0.271f };
+        }
+        throw std::invalid_argument("Unexpected direction");
+    }
+
+    const char* toString(LightDirection d)
+    {
+        return d == LightDirection::Front ? "Front" : d == LightDirection::Side ? "Side" : "Back";
+    }
+
+    struct Options
+    {
+        std::string cloud;
+        uint32_t width = 512, height = 256;                                       // Tasks.cpp:49-50
+        uint32_t spp = 0;                                                         // 0 = until converged
+        Cloud::Rendering::Mode mode = Cloud::Rendering::Mode::SunAndSkyAllScatter;
+        std::vector<LightDirection> lights = { LightDirection::Side, LightDirection::Back };   // Tasks.cpp:108-109
+        float sizeM = 7000.f;                                                     // main.cpp:63
+        std::string outDir = ".", dataDir;
+        bool fused = true;
+    };
+
+    using LazyTask = std::function<std::shared_ptr<Scene>()>;
+
+    LazyTask renderCloudSingleTask(const Options& opt, LightDirection lightDirection)   // Tasks.cpp:67-102
+    {
+        return [=]()
+        {
+            auto context = std::make_shared<Context>();
+            auto resources = std::make_shared<Resources>(context);
+            // installSceneSetup (installers.cpp:65-105)
+            const float3 direction = normalize(getLightDirection(lightDirection));
+            SceneDescription scene{
+                Cloud{ Cloud::Rendering{ 1.0f / 512.f, opt.mode },
+                       Cloud::Model{ opt.cloud, Cloud::Model::Mipmaps::On, Cloud::Model::Size{ Meter{ opt.sizeM } } } },
+                DirectionalLight{ direction, Color{ 1, 1, 1 }, 1e6f } };
+            std::string stem = std::filesystem::path(opt.cloud).filename().string();
+            std::replace(stem.begin(), stem.end(), ':', '_');
+            auto outputPath = std::filesystem::path(opt.outDir) / (stem + "." + toString(lightDirection) + "." + PathTracingRenderer::NAME + ".pfm");
+            // installFramework + installApp: Sun, VDBCloud, CloudMaterial, Camera in this order (installers.cpp:28-38)
+            auto renderer = std::make_shared<PathTracingRenderer>(context);
+            auto sun = std::make_shared<Sun>(std::make_shared<DirectionalLight>(scene.light), context);
+            auto cloud = std::make_shared<VDBCloud>(std::make_shared<Cloud::Model>(scene.cloud.model), context, resources);
+            auto material = std::make_shared<CloudMaterial>(std::make_shared<Cloud::Rendering>(scene.cloud.rendering), context);
+            auto camera = std::make_shared<Camera>(std::make_shared<Camera::Settings>(opt.width, opt.height, outputPath), context, renderer);
+            camera->completed = false;                                            // Tasks.cpp:97-98
+            camera->maxSubframes = opt.spp;
+            camera->fused = opt.fused;
+            std::vector<std::shared_ptr<SceneItem>> items{ sun, cloud, material, camera };
+            return std::make_shared<Scene>(items, context, opt.dataDir);
+        };
+    }
+}
+
+int main(int argc, char* argv[])
+{
+    try
+    {
+        Options opt;
+        if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused]\n"; return 2; }
+        opt.cloud = argv[1];
+        opt.dataDir = (std::filesystem::path(argv[0]).parent_path() / ".." / "data").string();
+        for (int i = 2; i < argc; i++)
+        {
+            const std::string a = argv[i];
+            auto next = [&]() { if (i + 1 >= argc) throw std::invalid_argument("missing value for " + a); return std::string(argv[++i]); };
+            if (a == "--size") { if (std::sscanf(next().c_str(), "%ux%u", &opt.width, &opt.height) != 2) throw std::invalid_argument("--size WxH"); }
+            else if (a == "--spp") opt.spp = (uint32_t)std::stoul(next());
+            else if (a == "--size-m") opt.sizeM = std::stof(next());
+            else if (a == "--out") opt.outDir = next();
+            else if (a == "--data") opt.dataDir = next();
+            else if (a == "--unfused") opt.fused = false;
+            else if (a == "--mode")
+            {
+                const std::string m = next();
+                if (m == "total") opt.mode = Cloud::Rendering::Mode::SunAndSkyAllScatter;
+                else if (m == "multi") opt.mode = Cloud::Rendering::Mode::SunMultipleScatter;
+                else if (m == "single") opt.mode = Cloud::Rendering::Mode::SunSingleScatter;
+                else throw std::invalid_argument("Invalid Render Mode");           // CloudMaterial.cpp:62
+            }
+            else if (a == "--light")
+            {
+                const std::string l = next();
+                opt.lights = { l == "Front" ? LightDirection::Front : l == "Back" ? LightDirection::Back : LightDirection::Side };
+            }
+            else throw std::invalid_argument("unknown option " + a);
+        }
+
+        std::queue<LazyTask> tasks;                                               // Tasks::renderCloud, Tasks.cpp:104-112
+        for (auto l : opt.lights) tasks.push(renderCloudSingleTask(opt, l));
+
+        while (!tasks.empty())                                                    // GuiExecutionLoop::getNextTask
+        {
+            auto scene = tasks.front()();
+            tasks.pop();
+            scene->init();
+            while (!scene->isCompleted())                                         // glutDisplay, GuiExecutionLoop.cpp:114-128
+            {
+                const auto t1 = std::chrono::steady_clock::now();
+                scene->update();
+                const auto t2 = std::chrono::steady_clock::now();
+                std::cout << "MS/FRAME " << std::chrono::duration<double, std::milli>(t2 - t1).count() << std::endl;
+            }
+        }
+        return 0;
+    }
+    catch (const std::exception& e)                                               // main.cpp:65-76
+    {
+        std::cout << e.what() << std::endl;
+        return 1;
+    }
+}

@@ -122,6 +122,9 @@ typedef struct CtScene {
 
 #define CT_FLAG_NONE 0u
 #define CT_FLAG_SIMPLE_KERNEL 1u /* one thread per pixel, nested loops (A/B + cross-check only) */
+#define CT_FLAG_LIGHT_NORMALIZED 2u /* light_direction already went through the reference's two
+                                       normalisations (a host that mirrors installSceneSetup +
+                                       DirectionalLight); use it as is */
 
 /* Deterministic work counters of everything rendered since create/ct_reset
  * (the algorithmic-bytes figure is built from these). */

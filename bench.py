@@ -39,12 +39,16 @@ def parse_args():
     ap.add_argument("--volume", type=int, default=512, help="density texture edge (texels)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp-per-step", type=int, default=64,
-                    help="subframes per progressive batch (one estimator launch + one accumulate launch)")
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="subframes per progressive batch (one estimator launch + one accumulate launch); "
+                         "default 64 x n_gpus, i.e. a constant number of samples per GPU per launch")
     ap.add_argument("--mode", type=int, default=0, help="0 totalRadiance (Mie multi-scatter + NEE)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--simple-kernel", action="store_true", help="A/B: one thread per pixel, nested loops")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the N>1 code path on a box with one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     return ap.parse_args()
 
 
@@ -97,12 +101,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libcloudtrace has no CPU fallback)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
-    W, H, S = args.width, args.height, args.spp_per_step
+    W, H = args.width, args.height
+    S = args.spp_per_step if args.spp_per_step > 0 else 64 * world
     t_setup = time.perf_counter()
     tex = ds.make_procedural_cloud(args.volume)
     flags = _lib.CT_FLAG_SIMPLE_KERNEL if args.simple_kernel else 0
@@ -137,7 +147,7 @@ def main():
     k1 = tr.counters()
     r1, a1, l1 = tr.kernel_time()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -182,7 +192,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{args.volume}^3 procedural density, {W}x{H}, progressive, {S} spp per step "
-                        f"(BASELINE.json configs[{2 if world == 1 else 3}]: 1024 spp job = {1024 // max(S,1)} such steps), "
+                        f"(BASELINE.json configs[{2 if world == 1 else 3}]: 1024 spp job = {max(1024 // max(S, 1), 1)} such steps), "
                         f"mode {('totalRadiance','multipleScatterSunRadiance','singleScatterSunRadiance')[args.mode]} "
                         "(Mie multi-scatter + NEE), estimator MARCH (reference-faithful), max_depth 2000",
             "volume": args.volume, "width": W, "height": H, "spp_per_step": S,

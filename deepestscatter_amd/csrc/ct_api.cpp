@@ -37,8 +37,8 @@ struct CtHandle_ {
     uint16_t *d_guide = nullptr;
     float4 *d_frame = nullptr, *d_mean = nullptr, *d_m2 = nullptr;
     uchar4 *d_screen = nullptr;
-    float4 *d_frames = nullptr; // batch scratch [S][H][W]
-    uint32_t frames_capacity = 0; // in subframes
+    float4 *d_frames = nullptr; // batch scratch [S][stride] (compact) or [S][H][W] (simple kernel)
+    size_t frames_capacity = 0; // in float4
     // work queue of the persistent kernel (rebuilt when the camera moves)
     float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
     uint32_t *d_pixels = nullptr;     // this shard's box-hitting pixels, padded to groups of 64
@@ -609,9 +609,19 @@ static int tune_order(CtHandle h, uint32_t measured_subframes)
     return CT_OK;
 }
 
+// Entries of one subframe in the batch scratch: the padded pixel list (compact) or the frame (simple).
+static size_t frame_stride(CtHandle h)
+{
+    if (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) {
+        return (size_t)h->scene.width * h->scene.height;
+    }
+    return (size_t)h->n_groups * 64;
+}
+
 static int ensure_frames(CtHandle h, uint32_t S)
 {
-    if (S <= h->frames_capacity) {
+    const size_t need = std::max<size_t>((size_t)S * frame_stride(h), 1);
+    if (need <= h->frames_capacity) {
         return CT_OK;
     }
     if (h->d_frames) {
@@ -620,8 +630,8 @@ static int ensure_frames(CtHandle h, uint32_t S)
         h->d_frames = nullptr;
         h->frames_capacity = 0;
     }
-    HIPCHK(h, dmalloc(&h->d_frames, (size_t)S * h->scene.width * h->scene.height));
-    h->frames_capacity = S;
+    HIPCHK(h, dmalloc(&h->d_frames, need));
+    h->frames_capacity = need;
     return CT_OK;
 }
 
@@ -641,8 +651,10 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
             return rc;
         }
     }
+    const bool dense = (frames == h->d_frame);
     BatchArgs ba{};
     ba.frames = frames;
+    ba.frame_stride = (simple || dense) ? 0u : h->n_groups * 64u;
     ba.primary = h->d_primary;
     ba.pixels = h->d_pixels;
     ba.job_group = h->d_job_group;
@@ -673,9 +685,14 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     if (accumulate) {
-        HIPCHK(h, launch_accumulate_batch(frames, simple ? nullptr : h->d_primary, h->d_mean, h->d_m2, first, S,
-                                          h->scene.width, h->scene.height, h->scene.shard_index,
-                                          h->scene.shard_count, h->stream));
+        if (simple || dense) {
+            HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, first, S, h->scene.width, h->scene.height,
+                                              h->scene.shard_index, h->scene.shard_count, h->stream));
+        } else {
+            HIPCHK(h, launch_accumulate_list(frames, ba.frame_stride, h->d_pixels, h->n_groups * 64u, h->d_primary,
+                                             h->d_mean, h->d_m2, first, S, h->scene.width, h->scene.height,
+                                             h->scene.shard_index, h->scene.shard_count, h->stream));
+        }
     }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev[2]));
@@ -720,7 +737,7 @@ extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *fram
     }
     const float4 *src = frame_rgba_dev ? (const float4 *)frame_rgba_dev : h->d_frame;
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    HIPCHK(h, launch_accumulate_batch(src, nullptr, h->d_mean, h->d_m2, subframe_id, 1, h->scene.width, h->scene.height,
+    HIPCHK(h, launch_accumulate_batch(src, h->d_mean, h->d_m2, subframe_id, 1, h->scene.width, h->scene.height,
                                       h->scene.shard_index, h->scene.shard_count, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev[2]));
@@ -744,18 +761,17 @@ extern "C" int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint
     if (count == 0) {
         return CT_OK;
     }
-    // split so that the scratch stays <= 4 GiB and sample / pixel indices fit 32 bits
-    const uint64_t plane = (uint64_t)h->scene.width * h->scene.height;
-    uint64_t cap = std::min<uint64_t>((4ull << 30) / (plane * sizeof(float4)), 0xffffffffull / std::max<uint64_t>(plane, 1));
-    // the work queue is a 32-bit counter that every wave bumps once more after it ran dry
     if (h->queue_dirty && !(h->scene.flags & CT_FLAG_SIMPLE_KERNEL)) {
         const int rc = rebuild_queue(h);
         if (rc != CT_OK) {
             return rc;
         }
     }
-    cap = std::min<uint64_t>(cap, 0xffffull); // job_sub packs the subframe offset in 16 bits
-    cap = std::max<uint64_t>(std::min<uint64_t>(cap, 1024), 1);
+    // split so that the scratch stays <= 8 GiB, scratch indices fit 32 bits and the subframe offset fits
+    // the 16 bits of job_sub
+    const uint64_t stride = std::max<uint64_t>(frame_stride(h), 1);
+    uint64_t cap = std::min<uint64_t>((8ull << 30) / (stride * sizeof(float4)), 0xffffffffull / stride);
+    cap = std::max<uint64_t>(std::min<uint64_t>(cap, 0xffffull), 1);
     uint32_t done = 0;
     while (done < count) {
         const uint32_t S = (uint32_t)std::min<uint64_t>(cap, count - done);

@@ -14,7 +14,11 @@ constexpr int kStatCount = 16;      // scheduler diagnostics (ct_debug_stats)
 
 // One progressive batch: subframes first .. first+S-1 of the handle's own tiles.
 struct BatchArgs {
-    float4 *frames;            // [S][H][W] per-sample results (frameResultBuffer x S)
+    // per-sample results (frameResultBuffer x S).  Compact form: frames[s * frame_stride + e] for
+    // entry e of the pixel list (only this shard's box-hitting pixels exist); dense form
+    // (frame_stride == 0): frames[pixel], one full W x H frame, used by ct_render_subframe.
+    float4 *frames;
+    uint32_t frame_stride;
     const float4 *primary;     // 2 float4 per pixel: cached primary ray (primary_rays_kernel)
     const uint32_t *pixels;    // this shard's box-hitting pixels, 64 per group, 0xffffffff padded
     // job list: job j renders subframes [begin, begin+count) of pixel group job_group[j];
@@ -54,9 +58,13 @@ hipError_t launch_fill_frame(float4 *frame, uint32_t width, uint32_t height, uin
 hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_t shard_index,
                                 uint32_t shard_count, hipStream_t stream);
-hipError_t launch_accumulate_batch(const float4 *frames, const float4 *primary, float4 *mean, float4 *m2,
-                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
-                                   uint32_t shard_index, uint32_t shard_count, hipStream_t stream);
+hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
+                                   uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
+                                   uint32_t shard_count, hipStream_t stream);
+hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, const uint32_t *pixels,
+                                  uint32_t n_entries, const float4 *primary, float4 *mean, float4 *m2,
+                                  uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
+                                  uint32_t shard_index, uint32_t shard_count, hipStream_t stream);
 hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure,
                            float *column_sums, float *avg, uchar4 *screen, hipStream_t stream);
 hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,

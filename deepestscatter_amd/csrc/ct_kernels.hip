@@ -326,8 +326,6 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0;
 
-    const size_t plane = (size_t)sc.width * sc.height;
-
     for (;;) {
         // ---------------- regenerate ----------------
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
@@ -366,7 +364,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                     if (pixel != 0xffffffffu) {
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                        out_idx = (uint32_t)(s * plane + pixel);
+                        out_idx = ba.frame_stride ? s * ba.frame_stride + (g * 64u + l) : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         dir = mk3(p1.x, p1.y, p1.z);
@@ -699,8 +697,23 @@ hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_
 // Only this shard's pixels are touched; everything else stays exactly 0 so that a sum over
 // shards (RCCL) reproduces the single-GPU image bit for bit.
 // =============================================================================================
+CT_DEV void welford(float4 &mu, float4 &var, float4 nr, uint32_t subframe_id)
+{
+    const float w = 1.0f / (float)subframe_id;
+    float4 nm;
+    nm.x = mu.x + (nr.x - mu.x) * w;
+    nm.y = mu.y + (nr.y - mu.y) * w;
+    nm.z = mu.z + (nr.z - mu.z) * w;
+    nm.w = mu.w + (nr.w - mu.w) * w;
+    var.x = var.x + (nr.x - mu.x) * (nr.x - nm.x);
+    var.y = var.y + (nr.y - mu.y) * (nr.y - nm.y);
+    var.z = var.z + (nr.z - mu.z) * (nr.z - nm.z);
+    var.w = var.w + (nr.w - mu.w) * (nr.w - nm.w);
+    mu = nm;
+}
+
+// Dense form: frames[s][y][x] holds every pixel of this shard.
 __global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__restrict__ frames,
-                                                               const float4 *__restrict__ primary,
                                                                float4 *__restrict__ mean, float4 *__restrict__ m2,
                                                                uint32_t first_subframe, uint32_t S, uint32_t width,
                                                                uint32_t height, uint32_t shard_index,
@@ -716,34 +729,86 @@ __global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__r
     }
     const size_t pix = (size_t)y * width + x;
     const size_t plane = (size_t)width * height;
-    // pixels whose primary ray misses the box are never rendered: their sample is (0,0,0,1)
-    const bool rendered = primary == nullptr || primary[2 * pix].w != 0.f;
     float4 mu = mean[pix], var = m2[pix];
     for (uint32_t s = 0; s < S; s++) {
-        const float4 nr = rendered ? frames[s * plane + pix] : make_float4(0.f, 0.f, 0.f, 1.f);
-        const float w = 1.0f / (float)(first_subframe + s);
-        float4 nm;
-        nm.x = mu.x + (nr.x - mu.x) * w;
-        nm.y = mu.y + (nr.y - mu.y) * w;
-        nm.z = mu.z + (nr.z - mu.z) * w;
-        nm.w = mu.w + (nr.w - mu.w) * w;
-        var.x = var.x + (nr.x - mu.x) * (nr.x - nm.x);
-        var.y = var.y + (nr.y - mu.y) * (nr.y - nm.y);
-        var.z = var.z + (nr.z - mu.z) * (nr.z - nm.z);
-        var.w = var.w + (nr.w - mu.w) * (nr.w - nm.w);
-        mu = nm;
+        welford(mu, var, frames[s * plane + pix], first_subframe + s);
     }
     mean[pix] = mu;
     m2[pix] = var;
 }
 
-hipError_t launch_accumulate_batch(const float4 *frames, const float4 *primary, float4 *mean, float4 *m2,
-                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
-                                   uint32_t shard_index, uint32_t shard_count, hipStream_t stream)
+hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
+                                   uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
+                                   uint32_t shard_count, hipStream_t stream)
 {
     const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
-    hipLaunchKernelGGL(accumulate_batch_kernel, grid, block, 0, stream, frames, primary, mean, m2, first_subframe, S,
-                       width, height, shard_index, shard_count);
+    hipLaunchKernelGGL(accumulate_batch_kernel, grid, block, 0, stream, frames, mean, m2, first_subframe, S, width,
+                       height, shard_index, shard_count);
+    return hipGetLastError();
+}
+
+// Compact form, part 1: one thread per entry of the pixel list (this shard's box-hitting pixels).
+__global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__restrict__ frames, uint32_t frame_stride,
+                                                              const uint32_t *__restrict__ pixels, uint32_t n_entries,
+                                                              float4 *__restrict__ mean, float4 *__restrict__ m2,
+                                                              uint32_t first_subframe, uint32_t S)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) {
+        return;
+    }
+    const uint32_t pix = pixels[e];
+    if (pix == 0xffffffffu) {
+        return;
+    }
+    float4 mu = mean[pix], var = m2[pix];
+    for (uint32_t s = 0; s < S; s++) {
+        welford(mu, var, frames[(size_t)s * frame_stride + e], first_subframe + s);
+    }
+    mean[pix] = mu;
+    m2[pix] = var;
+}
+
+// Compact form, part 2: this shard's pixels whose primary ray misses the box are never rendered;
+// their sample is (0,0,0,1) every subframe (empty miss program, progressive.cu:44-46).
+__global__ __launch_bounds__(256) void accumulate_miss_kernel(const float4 *__restrict__ primary,
+                                                              float4 *__restrict__ mean, float4 *__restrict__ m2,
+                                                              uint32_t first_subframe, uint32_t S, uint32_t width,
+                                                              uint32_t height, uint32_t shard_index,
+                                                              uint32_t shard_count)
+{
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
+    const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= width || y >= height) {
+        return;
+    }
+    if (tile_owner(x / kTile, y / kTile, shard_count) != shard_index) {
+        return;
+    }
+    const size_t pix = (size_t)y * width + x;
+    if (primary[2 * pix].w != 0.f) {
+        return;
+    }
+    float4 mu = mean[pix], var = m2[pix];
+    for (uint32_t s = 0; s < S; s++) {
+        welford(mu, var, make_float4(0.f, 0.f, 0.f, 1.f), first_subframe + s);
+    }
+    mean[pix] = mu;
+    m2[pix] = var;
+}
+
+hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, const uint32_t *pixels,
+                                  uint32_t n_entries, const float4 *primary, float4 *mean, float4 *m2,
+                                  uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
+                                  uint32_t shard_index, uint32_t shard_count, hipStream_t stream)
+{
+    if (n_entries) {
+        hipLaunchKernelGGL(accumulate_list_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, stream, frames,
+                           frame_stride, pixels, n_entries, mean, m2, first_subframe, S);
+    }
+    const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
+    hipLaunchKernelGGL(accumulate_miss_kernel, grid, block, 0, stream, primary, mean, m2, first_subframe, S, width,
+                       height, shard_index, shard_count);
     return hipGetLastError();
 }
 

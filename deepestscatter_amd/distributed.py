@@ -26,7 +26,13 @@ def frame_reduce(local, dst: int = 0):
     disjoint and foreign pixels are exactly 0, so the sum is the merged frame."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(local, dst=dst, op=dist.ReduceOp.SUM)
+        if local.is_cuda and dist.get_backend() != "nccl":
+            # rehearsal on a backend without device collectives (gloo): stage through the host
+            host = local.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            local.copy_(host)
+        else:
+            dist.reduce(local, dst=dst, op=dist.ReduceOp.SUM)
     return local
 
 

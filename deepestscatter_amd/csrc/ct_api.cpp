@@ -269,6 +269,26 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.mode = s->mode;
     d.tiles_x = (s->width + kTile - 1) / kTile;
     d.tiles_y = (s->height + kTile - 1) / kTile;
+    d.regen_min = 8;
+    // measured: running the scatter phase as soon as any lane needs it beats waiting for a fuller
+    // phase (927 vs 877 Msamples/s); a waiting lane is latency added to a serial path
+    d.scatter_num = 0;
+    d.scatter_den = 1;
+    d.scatter_min = 1;
+    if (const char *e = getenv("CT_SCATTER_MIN")) {
+        d.scatter_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
+    }
+    // tuning knobs for experiments (schedule only; results never change)
+    if (const char *e = getenv("CT_REGEN_MIN")) {
+        d.regen_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
+    }
+    if (const char *e = getenv("CT_SCATTER_RATIO")) { // "num/den"
+        unsigned a = 1, b = 1;
+        if (sscanf(e, "%u/%u", &a, &b) == 2 && b > 0 && a < 1000 && b < 1000) {
+            d.scatter_num = a;
+            d.scatter_den = b;
+        }
+    }
 
     // apron: farthest texel a marching path can address: slack box + the steps it fetches
     // speculatively in one scheduler visit (kSpec in ct_kernels.hip, 8 allowed for here)

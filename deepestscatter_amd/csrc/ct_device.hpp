@@ -84,6 +84,9 @@ struct DevScene {
     uint32_t max_depth;
     int32_t mode;
     uint32_t tiles_x, tiles_y;
+    uint32_t regen_min;    // idle lanes that trigger a regeneration phase
+    uint32_t scatter_num, scatter_den; // run the scatter phase when nb * den > nm * num ...
+    uint32_t scatter_min;  // ... and at least this many lanes wait for it (or nobody marches)
 };
 
 // ---- RNG: random.cuh:34-70 (tea<4> with v1 = subframeId) -------------------

@@ -288,7 +288,6 @@ CT_DEV float inv_max_advance(const DevScene &sc, f3 stepv)
     return __builtin_amdgcn_rcpf(fmaxf(m, 1e-20f));
 }
 
-constexpr uint32_t kRegenMin = 8;   // idle lanes that trigger a regeneration phase
 constexpr int kSpec = 1;            // march steps fetched speculatively per scheduler visit
 
 CT_DEV uint32_t lane_rank(uint64_t mask)
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         // ---------------- regenerate ----------------
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (n_idle >= kRegenMin && !(drained && q_next == q_end)) {
+        if ((n_idle >= sc.regen_min || n_idle == 64u) && !(drained && q_next == q_end)) {
             if (q_next == q_end) {
                 uint32_t j = 0;
                 if (lane == 0) {
@@ -406,11 +405,11 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             if (drained && q_next == q_end) {
                 break;
             }
-            continue; // everything idle: go regenerate (n_idle == 64 >= kRegenMin)
+            continue; // everything idle: go regenerate
         }
 
         bool finished = false;
-        if (nb > nm) {
+        if (nb * sc.scatter_den > nm * sc.scatter_num && (nb >= sc.scatter_min || nm == 0)) {
             // ---------------- scatter: NEE + new direction (cloudRadianceMaterials.cu:53-61) ----------------
             if (STATS) {
                 st_scat += 1;

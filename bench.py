@@ -164,11 +164,17 @@ def main():
     # each sample writes (accumulation's 64 B/pixel/batch belongs to the second, tiny kernel)
     alg_bytes = 8 * lookups + 16 * dk["paths"]
     achieved = alg_bytes / (render_ms * 1e-3) / 1e9 if render_ms > 0 else 0.0
+    # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of this same command (PMC
+    # collection cannot run inside the timed process); profiles/pmc_latest.json holds the figure, its
+    # calibration and the launch configuration it is valid for.
     traffic = None
     pmc = ROOT / "profiles" / "pmc_latest.json"
-    if pmc.exists():
+    if pmc.exists() and world == 1 and not args.simple_kernel:
         try:
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            rec = json.loads(pmc.read_text())
+            lc = rec.get("launch_config", {})
+            if (lc.get("spp_per_step"), lc.get("volume"), lc.get("width"), lc.get("height")) == (S, args.volume, W, H):
+                traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {

@@ -21,7 +21,7 @@ EXPORTS = [
     "ct_create", "ct_destroy", "ct_last_error", "ct_set_stream", "ct_set_camera", "ct_render_subframe",
     "ct_accumulate", "ct_render_accumulate", "ct_reset", "ct_tonemap", "ct_is_converged", "ct_download",
     "ct_buffer_bytes", "ct_copy_to_device", "ct_device_ptr", "ct_subframes", "ct_set_subframes", "ct_counters", "ct_kernel_time",
-    "ct_debug_cdf_inversion", "ct_debug_stats", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_generate_mipmaps",
+    "ct_debug_cdf_inversion", "ct_debug_fetch_probe", "ct_debug_stats", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_generate_mipmaps",
     "ct_tile_owner", "ct_make_procedural_cloud",
 ]
 
@@ -109,6 +109,7 @@ def load():
         "ct_kernel_time": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "ct_debug_cdf_inversion": (i32, [vp, u32, u32, vp]),
         "ct_debug_stats": (i32, [vp, vp]),
+        "ct_debug_fetch_probe": (i32, [i32, u32, u32, C.POINTER(C.c_uint64)]),
         "ct_calculate_camera_variables": (i32, [vp, vp, vp, f32, f32, vp, vp, vp]),
         "ct_quantize_volume": (i32, [vp, vp, vp]),
         "ct_generate_mipmaps": (i32, [vp, vp, vp, C.c_size_t, C.POINTER(u32), C.POINTER(C.c_size_t), vp]),

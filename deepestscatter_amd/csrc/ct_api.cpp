@@ -1002,6 +1002,39 @@ extern "C" int ct_debug_stats(CtHandle h, uint64_t out[16])
     return CT_OK;
 }
 
+extern "C" int ct_debug_fetch_probe(int32_t device, uint32_t log2_lines, uint32_t repeats, uint64_t *sum_out)
+{
+    if (log2_lines < 10 || log2_lines > 28 || hipSetDevice(device) != hipSuccess) {
+        return fail(nullptr, CT_E_INVAL, "ct_debug_fetch_probe: bad device or size");
+    }
+    uint8_t *buf = nullptr;
+    unsigned long long *sum = nullptr;
+    const size_t bytes = (size_t)128 << log2_lines;
+    if (hipMalloc((void **)&buf, bytes) != hipSuccess || hipMalloc((void **)&sum, 8) != hipSuccess) {
+        if (buf) {
+            hipFree(buf);
+        }
+        return fail(nullptr, CT_E_NOMEM, "ct_debug_fetch_probe: out of device memory");
+    }
+    hipMemset(buf, 0, bytes);
+    hipMemset(sum, 0, 8);
+    hipError_t e = hipSuccess;
+    for (uint32_t r = 0; r < repeats && e == hipSuccess; r++) {
+        e = launch_fetch_probe(buf, log2_lines, (r & 1u) ? 72u : 25u, sum, nullptr); // odd repeats touch both 64-B halves
+    }
+    if (e == hipSuccess) {
+        e = hipDeviceSynchronize();
+    }
+    unsigned long long v = 0;
+    hipMemcpy(&v, sum, 8, hipMemcpyDeviceToHost);
+    hipFree(buf);
+    hipFree(sum);
+    if (sum_out) {
+        *sum_out = v;
+    }
+    return e == hipSuccess ? CT_OK : fail(nullptr, CT_E_HIP, "fetch probe failed: %s", hipGetErrorString(e));
+}
+
 extern "C" int ct_debug_cdf_inversion(CtHandle h, uint32_t first_u24, uint32_t count, uint32_t *k_host_out)
 {
     NEED(h);

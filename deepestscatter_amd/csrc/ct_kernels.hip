@@ -936,4 +936,30 @@ hipError_t launch_cdf_selftest(const float *cdf, const uint16_t *guide, uint32_t
     return hipGetLastError();
 }
 
+// =============================================================================================
+// PMC calibration probe: the estimator's memory access shape on a buffer far larger than the caches
+// =============================================================================================
+__global__ void fetch_probe_kernel(const uint8_t *__restrict__ buf, uint32_t line_mask, uint32_t magic,
+                                   uint32_t second_offset, unsigned long long *sum)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t line = (i * 2654435761u + 12345u) & line_mask; // odd multiplier: a bijection on 2^k lines
+    const uint8_t *p = buf + ((size_t)line << 7) + 13;
+    uint2 a, c;
+    __builtin_memcpy(&a, p, 8);
+    __builtin_memcpy(&c, p + second_offset, 8);
+    const uint32_t v = a.x ^ a.y ^ c.x ^ c.y;
+    if (v == magic) { // a run-time value the zeroed buffer never produces; keeps the loads alive
+        atomicAdd(sum, 1ull);
+    }
+}
+
+hipError_t launch_fetch_probe(const uint8_t *buf, uint32_t log2_lines, uint32_t second_offset,
+                              unsigned long long *sum, hipStream_t stream)
+{
+    const uint32_t n = 1u << log2_lines;
+    hipLaunchKernelGGL(fetch_probe_kernel, dim3(n / 256), dim3(256), 0, stream, buf, n - 1u, 0xdeadbeefu, second_offset, sum);
+    return hipGetLastError();
+}
+
 } // namespace ct

@@ -232,6 +232,13 @@ CT_API int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_
  * skipped (replayed) march steps, skip-loop trips (wave level), rest reserved. */
 CT_API int ct_debug_stats(CtHandle h, uint64_t out[16]);
 
+/* PMC calibration probe (no handle): allocates 2^log2_lines 128-byte lines on `device`, and has one
+ * thread per line issue the estimator's access pattern (two unaligned 8-byte loads at byte 13 and
+ * byte 38 of a pseudo-randomly chosen, never repeated line).  Under rocprofv3 --pmc FETCH_SIZE this
+ * tells how many bytes the counter reports per touched line.  Odd-numbered repeats move the second
+ * load to byte 85 so that both 64-byte halves of the line are touched.  Returns a checksum. */
+CT_API int ct_debug_fetch_probe(int32_t device, uint32_t log2_lines, uint32_t repeats, uint64_t *sum_out);
+
 /* Self-test hook: k(val) of the CDF inversion (cloud.cuh:162-180) for `count` consecutive 24-bit
  * random integers starting at first_u24, evaluated by the device code; cos(theta) = (2k+1)/65536-1. */
 CT_API int ct_debug_cdf_inversion(CtHandle h, uint32_t first_u24, uint32_t count, uint32_t *k_host_out);

@@ -12,6 +12,7 @@
 //   converged_kernel           Camera::isConverged (Camera.cpp:232-268)
 //
 // Compile with -ffp-contract=off: results must be bit-identical to oracle/ct_oracle.c.
+#include <algorithm>
 #include <cstdlib>
 
 #include "ct_internal.hpp"
@@ -565,7 +566,13 @@ LaunchShape persistent_shape(int device)
     hipDeviceProp_t prop;
     LaunchShape s{ 1024, 256 };
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
-        s.blocks = prop.multiProcessorCount * 6; // 6 x 256 threads per CU: LDS 24 KiB/block
+        // as many 256-thread blocks per CU as the kernel's registers and LDS (24 KiB) admit
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_persistent_kernel<0, false>, 256, 0) != hipSuccess ||
+            per_cu < 1) {
+            per_cu = 6;
+        }
+        s.blocks = prop.multiProcessorCount * std::min(per_cu, 8);
         if (const char *e = getenv("CT_BLOCKS_PER_CU")) {   // tuning knob for experiments
             const int v = atoi(e);
             if (v >= 1 && v <= 8) {

@@ -32,6 +32,23 @@ def load_mie_raw() -> tuple[np.ndarray, np.ndarray]:
     return np.ascontiguousarray(raw[:4096]), np.ascontiguousarray(raw[4096:])
 
 
+# Gpu::PointRadianceTask, PointRadianceTask.h:70-77 (40 bytes)
+POINT_TASK_DTYPE = np.dtype([("id", "<i4"), ("experimentCount", "<u4"), ("radiance", "<f4"),
+                             ("runningVariance", "<f4"), ("position", "<f4", 3), ("direction", "<f4", 3)])
+assert POINT_TASK_DTYPE.itemsize == 40
+
+
+def make_point_tasks(positions, directions, ids=None) -> np.ndarray:
+    """PointRadianceTask(id, position, direction) x N (PointRadianceTask.h:15-18)."""
+    positions = np.asarray(positions, np.float32).reshape(-1, 3)
+    directions = np.asarray(directions, np.float32).reshape(-1, 3)
+    t = np.zeros(len(positions), POINT_TASK_DTYPE)
+    t["id"] = np.arange(len(positions)) if ids is None else ids
+    t["position"] = positions
+    t["direction"] = directions
+    return t
+
+
 def _p(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -183,6 +200,13 @@ class CloudTracer:
 
     def render_accumulate(self, first_subframe_id: int, count: int):
         check(self.L.ct_render_accumulate(self.h, first_subframe_id, count), self.h)
+
+    def point_radiance_launch(self, tasks: np.ndarray, first_frame_id: int, launches: int) -> np.ndarray:
+        """`launches` launches of estimateEmission (pointEmissionCamera.cu:20-40) over `tasks`
+        (POINT_TASK_DTYPE), updated in place and returned."""
+        assert tasks.dtype == POINT_TASK_DTYPE and tasks.flags.c_contiguous
+        check(self.L.ct_point_radiance_launch(self.h, _p(tasks), len(tasks), first_frame_id, launches), self.h)
+        return tasks
 
     def reset(self):
         check(self.L.ct_reset(self.h), self.h)

@@ -809,6 +809,92 @@ extern "C" int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint
     return CT_OK;
 }
 
+static_assert(sizeof(CtPointRadianceTask) == 40, "Gpu::PointRadianceTask is 40 bytes (PointRadianceTask.h:70-77)");
+
+extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_host, uint32_t count,
+                                        uint32_t first_frame_id, uint32_t launches)
+{
+    NEED(h);
+    if (!tasks_host || count == 0 || launches == 0 || launches > 0xffffu || count > (1u << 24)) {
+        return fail(h, CT_E_INVAL, "ct_point_radiance_launch: need 1..2^24 tasks and 1..65535 launches");
+    }
+    if (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) {
+        return fail(h, CT_E_INVAL, "point radiance tasks need the persistent kernel");
+    }
+    const uint32_t n_pad = (count + 63u) & ~63u, n_groups = n_pad / 64u;
+    if ((uint64_t)n_pad * launches > 0xffffffffull) {
+        return fail(h, CT_E_INVAL, "too many task-launches for one call");
+    }
+    // job list: every group of 64 tasks, `launches` frames in jobs of up to 8
+    std::vector<uint32_t> jg, js;
+    for (uint32_t g = 0; g < n_groups; g++) {
+        for (uint32_t s0 = 0; s0 < launches; s0 += 8) {
+            jg.push_back(g);
+            js.push_back(s0 | (std::min(8u, launches - s0) << 16));
+        }
+    }
+    void *d_tasks = nullptr;
+    float4 *d_primary = nullptr, *d_frames = nullptr;
+    uint32_t *d_pixels = nullptr, *d_jg = nullptr, *d_js = nullptr, *d_cost = nullptr;
+    auto cleanup = [&]() {
+        for (void *p : { d_tasks, (void *)d_primary, (void *)d_frames, (void *)d_pixels, (void *)d_jg, (void *)d_js,
+                         (void *)d_cost }) {
+            if (p) {
+                hipFree(p);
+            }
+        }
+    };
+    auto run = [&]() -> int {
+        HIPCHK(h, hipMalloc(&d_tasks, (size_t)count * sizeof(CtPointRadianceTask)));
+        HIPCHK(h, dmalloc(&d_primary, 2 * (size_t)n_pad));
+        HIPCHK(h, dmalloc(&d_frames, (size_t)n_pad * launches));
+        HIPCHK(h, dmalloc(&d_pixels, n_pad));
+        HIPCHK(h, dmalloc(&d_jg, jg.size()));
+        HIPCHK(h, dmalloc(&d_js, js.size()));
+        HIPCHK(h, dmalloc(&d_cost, n_groups));
+        HIPCHK(h, hipMemcpyAsync(d_tasks, tasks_host, (size_t)count * sizeof(CtPointRadianceTask),
+                                 hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_jg, jg.data(), jg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_js, js.data(), js.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(d_cost, 0, n_groups * sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(uint32_t), h->stream));
+        HIPCHK(h, launch_point_rays(h->dev, d_tasks, count, n_pad, d_primary, d_pixels, h->stream));
+        BatchArgs ba{};
+        ba.frames = d_frames;
+        ba.frame_stride = n_pad;
+        ba.primary = d_primary;
+        ba.pixels = d_pixels;
+        ba.job_group = d_jg;
+        ba.job_sub = d_js;
+        ba.cost = d_cost;
+        ba.n_jobs = (uint32_t)jg.size();
+        ba.first_subframe = first_frame_id;
+        ba.S = launches;
+        ba.queue = h->d_queue;
+        ba.counters = h->d_counters;
+        ba.stats = h->d_counters + kCounterCount + 1;
+        HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+        HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+        HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+        HIPCHK(h, launch_point_accumulate(d_frames, n_pad, d_tasks, count, launches, h->stream));
+        HIPCHK(h, hipMemcpyAsync(tasks_host, d_tasks, (size_t)count * sizeof(CtPointRadianceTask),
+                                 hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+        h->render_ms += ms;
+        h->launches += 1;
+        h->host_paths += (unsigned long long)count * launches;
+        return CT_OK;
+    };
+    const int rc = run();
+    if (rc != CT_OK) {
+        hipStreamSynchronize(h->stream);
+    }
+    cleanup();
+    return rc;
+}
+
 extern "C" int ct_reset(CtHandle h)
 {
     NEED(h);

@@ -73,6 +73,10 @@ hipError_t launch_cdf_selftest(const float *cdf, const uint16_t *guide, uint32_t
                                uint32_t *k_out, hipStream_t stream);
 hipError_t launch_fetch_probe(const uint8_t *buf, uint32_t log2_lines, uint32_t second_offset,
                               unsigned long long *sum, hipStream_t stream);
+hipError_t launch_point_rays(const DevScene &sc, const void *tasks, uint32_t n, uint32_t n_pad, float4 *primary,
+                             uint32_t *pixels, hipStream_t stream);
+hipError_t launch_point_accumulate(const float4 *frames, uint32_t stride, void *tasks, uint32_t n, uint32_t launches,
+                                   hipStream_t stream);
 LaunchShape persistent_shape(int device);
 
 } // namespace ct

@@ -244,6 +244,78 @@ hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t 
     return hipGetLastError();
 }
 
+// estimateEmission's ray setup (pointEmissionCamera.cu:22-31): the same closest-hit prologue for
+// an arbitrary origin/direction; launchID is 1-D, so the seed base is i*4096 + 0.
+struct PointTask {
+    int32_t id;
+    uint32_t experimentCount;
+    float radiance, runningVariance;
+    float px, py, pz, dx, dy, dz;
+};
+
+__global__ __launch_bounds__(256) void point_rays_kernel(DevScene sc, const PointTask *__restrict__ tasks, uint32_t n,
+                                                         uint32_t n_pad, float4 *__restrict__ primary,
+                                                         uint32_t *__restrict__ pixels)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) {
+        return;
+    }
+    if (i >= n) {
+        pixels[i] = 0xffffffffu;
+        return;
+    }
+    pixels[i] = i;
+    const PointTask t = tasks[i];
+    const f3 o = mk3(t.px, t.py, t.pz), d = mk3(t.dx, t.dy, t.dz);
+    float t_hit = 0;
+    const bool hit = intersect_box(sc, o, d, t_hit);
+    f3 pos = add3(o, scale3(d, t_hit));
+    pos = add3(pos, scale3(mk3(sc.bx, sc.by, sc.bz), 0.5f));
+    const f3 dir = normalize3(d);
+    primary[2 * (size_t)i] = make_float4(pos.x, pos.y, pos.z, hit ? 1.f : 0.f);
+    primary[2 * (size_t)i + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(i * 4096u));
+}
+
+// PointRadianceTask::addExperimentResult (PointRadianceTask.h:40-51) for `launches` results in order.
+__global__ __launch_bounds__(256) void point_accumulate_kernel(const float4 *__restrict__ frames, uint32_t stride,
+                                                               PointTask *__restrict__ tasks, uint32_t n,
+                                                               uint32_t launches)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    PointTask t = tasks[i];
+    for (uint32_t f = 0; f < launches; f++) {
+        const float new_radiance = frames[(size_t)f * stride + i].x;
+        t.experimentCount++;
+        const float N = (float)t.experimentCount;
+        const float new_weight = (float)(1.0 / (double)N);
+        const float previous_mean = t.radiance;
+        const float new_mean = t.radiance + (new_radiance - previous_mean) * new_weight;
+        t.radiance = new_mean;
+        t.runningVariance += (new_radiance - previous_mean) * (new_radiance - new_mean);
+    }
+    tasks[i] = t;
+}
+
+hipError_t launch_point_rays(const DevScene &sc, const void *tasks, uint32_t n, uint32_t n_pad, float4 *primary,
+                             uint32_t *pixels, hipStream_t stream)
+{
+    hipLaunchKernelGGL(point_rays_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, stream, sc,
+                       (const PointTask *)tasks, n, n_pad, primary, pixels);
+    return hipGetLastError();
+}
+
+hipError_t launch_point_accumulate(const float4 *frames, uint32_t stride, void *tasks, uint32_t n, uint32_t launches,
+                                   hipStream_t stream)
+{
+    hipLaunchKernelGGL(point_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, frames, stride,
+                       (PointTask *)tasks, n, launches);
+    return hipGetLastError();
+}
+
 // frameResultBuffer before a single-subframe render: (0,0,0,1) for this shard's pixels (misses
 // keep that value: empty miss program, progressive.cu:44-46), (0,0,0,0) for foreign pixels.
 __global__ void fill_frame_kernel(float4 *__restrict__ frame, uint32_t width, uint32_t height, uint32_t shard_index,
@@ -367,6 +439,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                         out_idx = ba.frame_stride ? s * ba.frame_stride + (g * 64u + l) : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
+                        const bool hit = p0.w != 0.f; // image jobs list hitting pixels only; point tasks may miss
                         dir = mk3(p1.x, p1.y, p1.z);
                         seed = tea4(__float_as_uint(p1.w), ba.first_subframe + s); // :21
                         rad = mk3(0, 0, 0);
@@ -375,7 +448,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                             dir = new_direction(lds.cdf, lds.guide, seed, dir);  // :86
                         }
                         // first loop test + depth bump (:28-34); mode 2 has no loop (:134)
-                        bool go = in_box(sc, pos);
+                        bool go = hit && in_box(sc, pos);
                         if (MODE != 2 && go) {
                             depth = 1;
                             if (depth == sc.max_depth) {

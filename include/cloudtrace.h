@@ -197,6 +197,28 @@ CT_API int ct_tonemap(CtHandle h, float exposure, uint8_t *rgba_host, float *avg
  * fewer than 500 pixels are outside the 95 % interval; *unconverged_pixels_out optional. */
 CT_API int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unconverged_pixels_out);
 
+/* ---- radiance samples: the estimator over (point, direction) tasks -------------------------- */
+
+/* Gpu::PointRadianceTask, src/CUDA/PointRadianceTask.h:12-78 (40 bytes, same field order). */
+typedef struct CtPointRadianceTask {
+    int32_t id;
+    uint32_t experimentCount;
+    float radiance;          /* running mean of prd.result.x */
+    float runningVariance;   /* running M2 */
+    float position[3];       /* ray origin, world coordinates (box centred at 0) */
+    float direction[3];      /* ray direction (need not be normalised) */
+} CtPointRadianceTask;
+
+/* `launches` consecutive launches of estimateEmission (src/CUDA/pointEmissionCamera.cu:20-40) over
+ * tasks[0..count): for frame = first_frame_id .. first_frame_id+launches-1, thread i traces one path
+ * from (position, direction) with the handle's render mode (the reference uses SunMultipleScatter,
+ * Tasks.cpp:135), seed tea<4>(i*4096, frame), and folds prd.result.x into task i with
+ * PointRadianceTask::addExperimentResult (:40-51), in frame order.  tasks_host is updated in place.
+ * This is the device part of RadianceCollector::update (RadianceCollector.cpp:88-96); replication,
+ * merging, convergence and rescheduling stay with the caller. */
+CT_API int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_host, uint32_t count,
+                                    uint32_t first_frame_id, uint32_t launches);
+
 /* ---- data access -------------------------------------------------------------------- */
 
 /* BufferBind<T>(buffer) map/copy, src/Util/BufferBind.h:11-74 (e.g. Camera.cpp:161,239-240).

@@ -508,6 +508,76 @@ ORC_API void orc_point_radiance(const OrcScene *s, uint32_t launch_id, uint32_t 
     }
 }
 
+/* Gpu::PointRadianceTask (src/CUDA/PointRadianceTask.h:12-78), 40 bytes. */
+typedef struct OrcPointTask {
+    int32_t id;
+    uint32_t experimentCount;
+    float radiance;
+    float runningVariance;
+    float position[3];
+    float direction[3];
+} OrcPointTask;
+
+/* addExperimentResult, PointRadianceTask.h:40-51 (newWeight = 1.0 / N is a double division). */
+static void point_task_add(OrcPointTask *t, float new_radiance)
+{
+    t->experimentCount++;
+    const float N = (float)t->experimentCount;
+    const float new_weight = (float)(1.0 / (double)N);
+    const float previous_mean = t->radiance;
+    const float new_mean = t->radiance + (new_radiance - previous_mean) * new_weight;
+    t->radiance = new_mean;
+    t->runningVariance += (new_radiance - previous_mean) * (new_radiance - new_mean);
+}
+
+/* `launches` launches of estimateEmission (pointEmissionCamera.cu:20-40) over tasks[0..count):
+ * frame = first_frame .. first_frame+launches-1, launchID = task index. */
+ORC_API void orc_point_radiance_launch(const OrcScene *s, OrcPointTask *tasks, uint32_t count,
+                                       uint32_t first_frame, uint32_t launches, OrcCounters *counters, int32_t threads)
+{
+    Ctx c;
+    ctx_init(&c, s);
+    uint64_t paths = 0, hits = 0, dl = 0, il = 0, se = 0, dc = 0;
+#ifdef _OPENMP
+    if (threads <= 0) {
+        threads = omp_get_max_threads();
+    }
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads) reduction(+ : paths, hits, dl, il, se, dc)
+    for (int64_t i = 0; i < (int64_t)count; i++) {
+        OrcCounters k = { 0, 0, 0, 0, 0, 0 };
+        OrcPointTask *t = &tasks[i];
+        for (uint32_t f = 0; f < launches; f++) {
+            const uint32_t seed = orc_tea4((uint32_t)i * 4096u, first_frame + f);
+            const v3 rad = radiance_of_ray(&c, v3_make(t->position[0], t->position[1], t->position[2]),
+                                           v3_make(t->direction[0], t->direction[1], t->direction[2]), seed, &k);
+            point_task_add(t, rad.x);
+        }
+        paths += k.paths; hits += k.box_hits; dl += k.density_lookups;
+        il += k.inscatter_lookups; se += k.scatter_events; dc += k.depth_capped;
+    }
+    if (counters) {
+        counters->paths += paths; counters->box_hits += hits; counters->density_lookups += dl;
+        counters->inscatter_lookups += il; counters->scatter_events += se; counters->depth_capped += dc;
+    }
+}
+
+/* PointRadianceTask::operator+= (:56-68): merge of a replica; note that the reference adds the
+ * two M2 values without the between-means term.  Returns -1 when the ids differ. */
+ORC_API int32_t orc_point_task_merge(OrcPointTask *into, const OrcPointTask *other)
+{
+    if (other->id != into->id) {
+        return -1;
+    }
+    const float new_weight = other->experimentCount * 1.0f / (into->experimentCount + other->experimentCount);
+    into->radiance += (other->radiance - into->radiance) * new_weight;
+    into->runningVariance += other->runningVariance;
+    into->experimentCount += other->experimentCount;
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Shadow volume: inScatter, src/CUDA/inScatter.cu:40-66 (host side VDBCloud.cpp:57-86).
  * Sample THEN step; marches 1/sampleStep steps toward -lightDirection; early out when

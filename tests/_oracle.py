@@ -113,6 +113,10 @@ def lib(fast: bool = False):
     L.orc_point_radiance.argtypes = [C.POINTER(OrcScene), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(OrcCounters)]
     L.orc_inscatter.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_int32]
+    L.orc_point_radiance_launch.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.POINTER(OrcCounters), C.c_int32]
+    L.orc_point_task_merge.restype = C.c_int32
+    L.orc_point_task_merge.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_camera_variables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_quantize_volume.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -255,6 +259,13 @@ class Oracle:
                 frame[~mask] = 0
             self.L.orc_accumulate(_ptr(frame), _ptr(mean), _ptr(m2), sid, self.width * self.height)
         return mean, m2
+
+    def point_radiance_launch(self, tasks: np.ndarray, first_frame: int, launches: int) -> np.ndarray:
+        """Oracle twin of ct_point_radiance_launch; `tasks` has the 40-byte PointRadianceTask layout."""
+        assert tasks.dtype.itemsize == 40 and tasks.flags.c_contiguous
+        self.L.orc_point_radiance_launch(C.byref(self.scene), _ptr(tasks), len(tasks), first_frame, launches,
+                                         C.byref(self.counters), self.threads)
+        return tasks
 
     def point_radiance(self, launch_id: int, subframe_id: int, origin, direction) -> np.ndarray:
         o = np.asarray(origin, np.float32)

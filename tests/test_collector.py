@@ -1,0 +1,147 @@
+"""Radiance-sample producer: host logic of RadianceCollector and the wire
+format of its output.  The CPU tests drive the collector with the ORACLE as the device part; the
+GPU test checks ct_point_radiance_launch against the oracle bit for bit."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import deepestscatter_amd as ds
+from deepestscatter_amd import collector as col
+from conftest import sphere_volume
+
+
+def sample_tasks(n, seed=0):
+    rng = np.random.default_rng(seed)
+    pos = (rng.random((n, 3), dtype=np.float32) - 0.5) * 0.5          # inside the cloud's box
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pos[0] = (3.0, 0.0, 0.0)
+    d[0] = (1.0, 0.0, 0.0)                                              # a ray that misses the box
+    pos[1] = (2.0, 0.1, 0.0)
+    d[1] = (-2.0, 0.0, 0.0)                                             # enters from outside, unnormalised direction
+    return pos, d
+
+
+def test_result_and_scatter_sample_wire_format():
+    # canonical proto3 bytes (field 1 fixed32 tag 0x0d, field 2 varint tag 0x10)
+    assert col.encode_result(1.5, True) == b"\x0d\x00\x00\xc0\x3f\x10\x01"
+    assert col.encode_result(0.0, False) == b""
+    assert col.decode_result(col.encode_result(0.25, True)) == (0.25, True)
+    try:
+        from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    except Exception:
+        pytest.skip("protobuf runtime not importable")
+    fd = descriptor_pb2.FileDescriptorProto(name="r.proto", package="Persistance", syntax="proto3")
+    m = fd.message_type.add(name="Result")
+    m.field.add(name="light_intensity", number=1, type=2, label=1)
+    m.field.add(name="is_converged", number=2, type=8, label=1)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Result = message_factory.GetMessageClass(pool.FindMessageTypeByName("Persistance.Result"))
+    for li, cv in [(1.5, True), (0.0, True), (3.25e-3, False)]:
+        assert Result(light_intensity=li, is_converged=cv).SerializeToString() == col.encode_result(li, cv)
+        r = Result.FromString(col.encode_result(li, cv))
+        assert (r.light_intensity, r.is_converged) == (np.float32(li), cv)
+    b = col.encode_scatter_sample(7, (0.5, 0.0, -1.25), (0.0, 1.0, 0.0))
+    assert col.decode_scatter_sample(b) == (7, (0.5, 0.0, -1.25), (0.0, 1.0, 0.0))
+
+
+def test_flat_dataset_roundtrip(tmp_path):
+    recs = [(2048 * 3 + i, col.encode_result(0.1 * i, True)) for i in range(5)]
+    col.write_flat_dataset(tmp_path / "r.flat", "Result", recs)
+    assert col.read_flat_dataset(tmp_path / "r.flat") == ("Result", recs)
+
+
+def test_merge_matches_the_oracle_restatement(oracle_lib):
+    import ctypes as C
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        a = np.zeros(1, ds.POINT_TASK_DTYPE)
+        b = np.zeros(1, ds.POINT_TASK_DTYPE)
+        a["experimentCount"], b["experimentCount"] = rng.integers(1, 5000, 2)
+        a["radiance"], b["radiance"] = rng.random(2)
+        a["runningVariance"], b["runningVariance"] = rng.random(2) * 10
+        ref = a.copy()
+        assert oracle_lib.orc_point_task_merge(ref.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == 0
+        got = a.copy()
+        col.merge_tasks(got[0], b[0])
+        assert got.tobytes() == ref.tobytes()
+    b["id"] = 9
+    with pytest.raises(ValueError):
+        col.merge_tasks(a[0], b[0])
+
+
+def test_collector_logic_with_oracle_backend():
+    """Replication, merge, convergence and rescheduling (RadianceCollector.cpp:73-192)."""
+    tex = sphere_volume(24, seed=7)
+    orc = O.Oracle(tex, 8, 8, mode=1, fast=True)
+    pos, d = sample_tasks(12)
+    c = col.RadianceCollector(orc.point_radiance_launch, pos, d, batch_start_id=4096, max_thread_count=48,
+                              launches_per_update=25)
+    assert c.task_repeat_count == 4 and c.threads_count == 48
+    assert list(c.tasks_buffer["id"][:8]) == [0, 0, 0, 0, 1, 1, 1, 1]
+    c.update()
+    # every replica ran 25 experiments; the representative merged 4 of them
+    assert c.frame_id == 25
+    done = c.get_converged_count()
+    total_exp = [int(t["experimentCount"]) for t in c.converged_tasks]
+    assert all(e == 100 for e in total_exp)
+    if not c.is_completed():
+        # unconverged tasks were re-packed with more replicas, keeping their statistics in slot 0
+        assert c.task_repeat_count == 48 // c.get_remaining_count()
+        assert int(c.tasks_buffer[0]["experimentCount"]) == 100
+        assert int(c.tasks_buffer[1]["experimentCount"]) == 0
+    for _ in range(40):
+        if c.is_completed():
+            break
+        c.update()
+    assert c.get_converged_count() >= done
+    # the missing ray has radiance 0: it only converges after > 1e5 experiments (:116-118)
+    ids_done = {int(t["id"]) for t in c.converged_tasks}
+    assert 0 not in ids_done or any(int(t["experimentCount"]) > 100000 for t in c.converged_tasks if int(t["id"]) == 0)
+    recs = c.results()
+    assert [k for k, _ in recs] == sorted(k for k, _ in recs) and all(k >= 4096 for k, _ in recs)
+    for _, payload in recs:
+        li, conv = col.decode_result(payload)
+        assert conv and li >= 0
+
+
+@pytest.mark.gpu
+def test_point_radiance_launch_bit_exact_on_gpu():
+    tex = sphere_volume(32, seed=11)
+    n = 150                                                        # not a multiple of 64
+    pos, d = sample_tasks(n, seed=5)
+    for mode in (1, 0):
+        tr = ds.CloudTracer(tex, width=8, height=8, mode=mode)
+        orc = O.Oracle(tex, 8, 8, mode=mode, fast=True)
+        got = tr.point_radiance_launch(ds.make_point_tasks(pos, d), 1, 7)
+        ref = orc.point_radiance_launch(ds.make_point_tasks(pos, d), 1, 7)
+        assert got.tobytes() == ref.tobytes()
+        # a second call continues the statistics (frames 8..12), like the reference's next update()
+        got = tr.point_radiance_launch(got, 8, 5)
+        ref = orc.point_radiance_launch(ref, 8, 5)
+        assert got.tobytes() == ref.tobytes()
+        assert int(got["experimentCount"][3]) == 12 and got["radiance"][0] == 0      # task 0 misses the box
+        c = tr.counters()
+        o = orc.counters.as_dict()
+        assert (c["density_lookups"], c["scatter_events"], c["depth_capped"]) == \
+               (o["density_lookups"], o["scatter_events"], o["depth_capped"])
+        tr.close()
+
+
+@pytest.mark.gpu
+def test_collector_end_to_end_on_gpu(tmp_path):
+    tex = sphere_volume(32, seed=12)
+    tr = ds.CloudTracer(tex, width=8, height=8, mode=1)             # SunMultipleScatter, Tasks.cpp:135
+    pos, d = sample_tasks(40, seed=9)
+    pos, d = pos[2:], d[2:]                                         # drop the contrived rays
+    c = col.RadianceCollector(tr.point_radiance_launch, pos, d, batch_start_id=2048, max_thread_count=2048)
+    for _ in range(30):
+        if c.is_completed():
+            break
+        c.update()
+    assert c.get_converged_count() > 0
+    col.write_flat_dataset(tmp_path / "res.flat", "Result", c.results())
+    table, recs = col.read_flat_dataset(tmp_path / "res.flat")
+    assert table == "Result" and len(recs) == c.get_converged_count()
+    tr.close()

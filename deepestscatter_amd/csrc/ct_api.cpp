@@ -341,18 +341,13 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.dbricks = h->d_dbricks;
     d.ibricks = h->d_ibricks;
     {
-        // free-space distance field over kBrick^3 bricks (DevScene::dist)
-        const int bias = ((apron + 1 + kBrick - 1) / kBrick) * kBrick;
-        const int gx = ((int)nx + 2 * bias + kBrick - 1) / kBrick + 1, gy = ((int)ny + 2 * bias + kBrick - 1) / kBrick + 1,
-                  gz = ((int)nz + 2 * bias + kBrick - 1) / kBrick + 1;
-        const size_t nb = (size_t)gx * gy * gz;
+        // free-space distance field on the brick grid itself, embedded as the bricks' meta byte
+        const size_t nb = (size_t)(bgx * bgy * bgz);
         HIPCHK(h, dmalloc(&h->d_dist, nb));
         HIPCHK(h, dmalloc(&h->d_dist_tmp, nb));
-        HIPCHK(h, launch_build_dist(h->d_density, nx, ny, nz, bias, gx, gy, gz, h->d_dist, h->d_dist_tmp, h->stream));
-        d.dist = h->d_dist;
-        d.dist_sy = gx;
-        d.dist_sz = gx * gy;
-        d.dist_bias = bias;
+        HIPCHK(h, launch_build_dist(h->d_density, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_dist,
+                                    h->d_dist_tmp, h->stream));
+        HIPCHK(h, launch_brick_meta(h->d_dist, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_dbricks, h->stream));
     }
     HIPCHK(h, launch_inscatter(d, h->d_inscatter, h->stream));
     HIPCHK(h, launch_build_bricks(h->d_inscatter, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_ibricks, h->stream));

@@ -60,12 +60,11 @@ struct DevScene {
     int32_t brick_bias;      // added to a texel index to make it non-negative (multiple of 4)
     int32_t brick_gx;        // bricks per row
     int32_t brick_gxy;       // bricks per slice
-    // empty-space distance field over kBrick^3-texel bricks: dist[brick] = Chebyshev distance (in
-    // bricks, capped) to the nearest brick that is not provably "free" (all texels a trilinear
-    // footprint based in it can touch are zero AND every position in it passes isInBox).
-    const uint8_t *dist;
-    int32_t dist_sy, dist_sz; // bricks per row / slice
-    int32_t dist_bias;        // texel offset added before the shift (multiple of kBrick, > apron)
+    // Byte 125 of every DENSITY brick is its meta byte: bits 0-6 = free-space distance D
+    // (Chebyshev distance, in bricks, capped, to the nearest brick that is not provably "free":
+    // all texels a trilinear footprint based in it can touch are zero), bit 7 = "interior" (every
+    // position whose base texel lies in the brick passes isInBox, and so does a scatter position
+    // backed off from it).  It rides in the cache line the footprint is read from.
     int32_t nx, ny, nz;    // texels
     float sx, sy, sz;      // box coordinate -> texel coordinate (textureScale * N)
     float bx, by, bz;      // bboxSize          (VDBCloud.cpp:104)
@@ -151,6 +150,25 @@ CT_DEV uint2 load_footprint(const DevScene &sc, const uint8_t *bricks, int32_t i
     return r;
 }
 
+// The same plus the brick's meta byte (one more load from the same cache line).
+CT_DEV uint2 load_footprint_meta(const DevScene &sc, const uint8_t *bricks, int32_t ix, int32_t iy, int32_t iz,
+                                 uint32_t &meta)
+{
+    const uint32_t x = (uint32_t)(ix + sc.brick_bias), y = (uint32_t)(iy + sc.brick_bias), z = (uint32_t)(iz + sc.brick_bias);
+    const uint32_t brick = __umul24(z >> 2, (uint32_t)sc.brick_gxy) + __umul24(y >> 2, (uint32_t)sc.brick_gx) + (x >> 2);
+    const uint32_t local = __umul24(z & 3u, 25u) + __umul24(y & 3u, 5u) + (x & 3u);
+    const uint8_t *base = bricks + ((size_t)brick << 7);
+    const uint8_t *p = base + local;
+    uint2 a, c;
+    __builtin_memcpy(&a, p, 8);
+    __builtin_memcpy(&c, p + 25, 8);
+    meta = base[125];
+    uint2 r;
+    r.x = __builtin_amdgcn_perm(a.y, a.x, 0x06050100u);
+    r.y = __builtin_amdgcn_perm(c.y, c.x, 0x06050100u);
+    return r;
+}
+
 // (int)floorf(x) in one instruction (v_cvt_flr_i32_f32); identical for every in-range x.
 CT_DEV int32_t floor_to_int(float x)
 {
@@ -172,18 +190,10 @@ CT_DEV float tex3_apron(const DevScene &sc, const uint8_t *bricks, f3 p)
 // The march splits the texture fetch in three so that several loads can be in flight and all-zero
 // cells can skip the filter: the cell load, the free-space distance of the brick a position is in,
 // and the filter at a position.
-CT_DEV uint2 fetch_cell(const DevScene &sc, const uint8_t *bricks, f3 p)
+CT_DEV uint2 fetch_cell(const DevScene &sc, const uint8_t *bricks, f3 p, uint32_t &meta)
 {
     const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
-    return load_footprint(sc, bricks, floor_to_int(x), floor_to_int(y), floor_to_int(z));
-}
-
-CT_DEV uint32_t fetch_dist(const DevScene &sc, f3 p)
-{
-    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
-    const int32_t bx = (floor_to_int(x) + sc.dist_bias) >> kBrickShift, by = (floor_to_int(y) + sc.dist_bias) >> kBrickShift,
-                  bz = (floor_to_int(z) + sc.dist_bias) >> kBrickShift;
-    return sc.dist[__mul24(bz, sc.dist_sz) + __mul24(by, sc.dist_sy) + bx];
+    return load_footprint_meta(sc, bricks, floor_to_int(x), floor_to_int(y), floor_to_int(z), meta);
 }
 
 CT_DEV float filter_at(const DevScene &sc, uint2 cell, f3 p)
@@ -302,6 +312,36 @@ CT_DEV bool intersect_box(const DevScene &sc, f3 o, f3 d, float &t_hit)
         return true;
     }
     return false;
+}
+
+// ---- log for the march's back-off: the argument xi/T is > 1 and finite (xi > T > 0), so ct_logf's
+// special cases (<= 0, inf, subnormal) can never fire; same instruction sequence otherwise. -----
+CT_DEV float logf_above_one(float x)
+{
+    const uint32_t u = ct_float_to_bits(x);
+    int32_t e = (int32_t)(u >> 23) - 126;
+    float m = ct_bits_to_float((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    const float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, m, -1.1514610310e-1f);
+    p = fmaf(p, m, 1.1676998740e-1f);
+    p = fmaf(p, m, -1.2420140846e-1f);
+    p = fmaf(p, m, 1.4249322787e-1f);
+    p = fmaf(p, m, -1.6668057665e-1f);
+    p = fmaf(p, m, 2.0000714765e-1f);
+    p = fmaf(p, m, -2.4999993993e-1f);
+    p = fmaf(p, m, 3.3333331174e-1f);
+    const float fe = (float)e;
+    float y = (p * m) * z;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    return fmaf(fe, 0.693359375f, m + y);
 }
 
 // ---- exp for the march: arguments are -sigma*step in (-87, 0], so ct_expf's range checks

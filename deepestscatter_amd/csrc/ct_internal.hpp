@@ -51,6 +51,8 @@ hipError_t launch_build_bricks(const uint8_t *texels, int nx, int ny, int nz, in
                                uint8_t *bricks, hipStream_t stream);
 hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
                              uint8_t *dist, uint8_t *scratch, hipStream_t stream);
+hipError_t launch_brick_meta(const uint8_t *dist, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
+                             uint8_t *bricks, hipStream_t stream);
 hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream);
 hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream);
 hipError_t launch_fill_frame(float4 *frame, uint32_t width, uint32_t height, uint32_t shard_index,

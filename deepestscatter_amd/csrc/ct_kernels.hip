@@ -90,6 +90,21 @@ __global__ void brick_free_kernel(const uint8_t *__restrict__ t, int nx, int ny,
     dist[b] = free_ ? (uint8_t)kDistMax : (uint8_t)0;
 }
 
+// Writes the meta byte (see DevScene) into byte 125 of every density brick.
+__global__ void brick_meta_kernel(const uint8_t *__restrict__ dist, int nx, int ny, int nz, int bias, int gx, int gy,
+                                  int gz, uint8_t *__restrict__ bricks)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= gx * gy * gz) {
+        return;
+    }
+    const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
+    const int x0 = bx * kBrick - bias, y0 = by * kBrick - bias, z0 = bz * kBrick - bias;
+    const bool interior = x0 >= 1 && y0 >= 1 && z0 >= 1 && x0 + kBrick - 1 <= nx - 3 && y0 + kBrick - 1 <= ny - 3 &&
+                          z0 + kBrick - 1 <= nz - 3;
+    bricks[((size_t)b << 7) + 125] = (uint8_t)(min((int)dist[b], 127) | (interior ? 0x80 : 0));
+}
+
 // One relaxation of the Chebyshev distance transform: d = min(d, 1 + min over the 26 neighbours).
 __global__ void brick_dist_relax_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int gx, int gy,
                                         int gz)
@@ -135,6 +150,15 @@ hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int 
             return e;
         }
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_brick_meta(const uint8_t *dist, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
+                             uint8_t *bricks, hipStream_t stream)
+{
+    const int total = gx * gy * gz;
+    hipLaunchKernelGGL(brick_meta_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, dist, nx, ny, nz, bias, gx,
+                       gy, gz, bricks);
     return hipGetLastError();
 }
 
@@ -361,7 +385,6 @@ CT_DEV float inv_max_advance(const DevScene &sc, f3 stepv)
     return __builtin_amdgcn_rcpf(fmaxf(m, 1e-20f));
 }
 
-constexpr int kSpec = 1;            // march steps fetched speculatively per scheduler visit
 
 CT_DEV uint32_t lane_rank(uint64_t mask)
 {
@@ -535,53 +558,37 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                         st_skip += (uint32_t)n;
                     }
                 }
-                // Speculative fetch of the next kSpec cells along the ray: the positions do not
-                // depend on the fetched data, so all loads go out together.  Consecutive steps
-                // mostly fall into the same 128-byte line, which is then fetched once per burst
-                // instead of once per step, and the dependent-latency chain is kSpec times shorter.
-                // Steps after a collision / exit are simply not consumed.
-                uint2 cell[kSpec];
-                {
-                    f3 p = pos;
-#pragma unroll
-                    for (int k = 0; k < kSpec; k++) {
-                        p = add3(p, stepv);
-                        cell[k] = fetch_cell(sc, sc.dbricks, p);
-                    }
-                    dfree = fetch_dist(sc, p);
+                pos = add3(pos, stepv);
+                uint32_t meta;
+                const uint2 cell = fetch_cell(sc, sc.dbricks, pos, meta);
+                dfree = meta & 0x7fu;
+                c_dl += 1;
+                if (STATS) {
+                    st_fetch += 1;
+                    st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
                 }
-#pragma unroll
-                for (int k = 0; k < kSpec; k++) {
-                    if (state == ST_MARCH) {
-                        pos = add3(pos, stepv);
-                        c_dl += 1;
-                        if (STATS) {
-                            st_fetch += 1;
-                            st_zero += ((cell[k].x | cell[k].y) == 0u) ? 1u : 0u;
-                        }
-                        bool collided = false;
-                        if ((cell[k].x | cell[k].y) != 0u) {
-                            // all-zero cells give density 0, exp(-0) = 1, T unchanged: nothing to evaluate
-                            const float density = filter_at(sc, cell[k], pos) * sc.density_multiplier;
-                            const float extinction = density * sc.sample_step;
-                            T *= expf_inrange(-extinction);
-                            if (xi > T) {
-                                collided = true;
-                                const float lg = ct_logf(xi / T);
-                                const float inv = 1.0f / density;
-                                pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
-                            }
-                        }
-                        if (!in_box(sc, pos)) {
-                            finished = true;      // left the box, or scattered outside it (:49-52)
-                            state = ST_IDLE;
-                        } else if (collided) {
-                            state = ST_BOUNCE;
-                        }
+                bool collided = false;
+                if ((cell.x | cell.y) != 0u) {
+                    // all-zero footprints give density 0, exp(-0) = 1, T unchanged: nothing to evaluate
+                    const float density = filter_at(sc, cell, pos) * sc.density_multiplier;
+                    const float extinction = density * sc.sample_step;
+                    T *= expf_inrange(-extinction);
+                    if (xi > T) {
+                        collided = true;
+                        const float lg = logf_above_one(xi / T);
+                        const float inv = 1.0f / density;
+                        pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
                     }
                 }
-                if (state != ST_MARCH) {
-                    dfree = 0; // the distance was fetched for a position this path never reached
+                // isInBox(pos) (no collision) / isInBox(scatterPos) (:49-52).  In an "interior" brick
+                // both are known to hold (see DevScene), so the six comparisons are skipped.
+                const bool inside = (meta & 0x80u) != 0u || in_box(sc, pos);
+                if (!inside) {
+                    finished = true;
+                    state = ST_IDLE;
+                } else if (collided) {
+                    state = ST_BOUNCE;
+                    dfree = 0;
                 }
             }
         }

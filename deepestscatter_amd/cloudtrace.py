@@ -208,6 +208,13 @@ class CloudTracer:
         check(self.L.ct_point_radiance_launch(self.h, _p(tasks), len(tasks), first_frame_id, launches), self.h)
         return tasks
 
+    def generate_scatter_samples(self, count: int, batch_seed: int = 0):
+        """generatePoints + firstScatterPosition: -> (positions [count,3], view directions [count,3])."""
+        pos = np.empty((count, 3), np.float32)
+        d = np.empty((count, 3), np.float32)
+        check(self.L.ct_generate_scatter_samples(self.h, count, batch_seed & 0xFFFFFFFF, _p(pos), _p(d)), self.h)
+        return pos, d
+
     def reset(self):
         check(self.L.ct_reset(self.h), self.h)
 

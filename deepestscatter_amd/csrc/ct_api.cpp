@@ -890,6 +890,35 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
     return rc;
 }
 
+extern "C" int ct_generate_scatter_samples(CtHandle h, uint32_t count, uint32_t batch_seed,
+                                           float *positions_host_out, float *directions_host_out)
+{
+    NEED(h);
+    if (!positions_host_out || !directions_host_out || count == 0 || count > (1u << 20)) {
+        return fail(h, CT_E_INVAL, "ct_generate_scatter_samples: need 1..2^20 samples and two output arrays");
+    }
+    float *d_pos = nullptr, *d_dir = nullptr;
+    auto run = [&]() -> int {
+        HIPCHK(h, dmalloc(&d_pos, 3 * (size_t)count));
+        HIPCHK(h, dmalloc(&d_dir, 3 * (size_t)count));
+        HIPCHK(h, launch_scatter_samples(h->dev, count, batch_seed, d_pos, d_dir, h->stream));
+        HIPCHK(h, hipMemcpyAsync(positions_host_out, d_pos, 3 * (size_t)count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(directions_host_out, d_dir, 3 * (size_t)count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return CT_OK;
+    };
+    const int rc = run();
+    if (rc != CT_OK) {
+        hipStreamSynchronize(h->stream);
+    }
+    for (void *p : { (void *)d_pos, (void *)d_dir }) {
+        if (p) {
+            hipFree(p);
+        }
+    }
+    return rc;
+}
+
 extern "C" int ct_reset(CtHandle h)
 {
     NEED(h);

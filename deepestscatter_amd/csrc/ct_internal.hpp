@@ -79,6 +79,8 @@ hipError_t launch_point_rays(const DevScene &sc, const void *tasks, uint32_t n, 
                              uint32_t *pixels, hipStream_t stream);
 hipError_t launch_point_accumulate(const float4 *frames, uint32_t stride, void *tasks, uint32_t n, uint32_t launches,
                                    hipStream_t stream);
+hipError_t launch_scatter_samples(const DevScene &sc, uint32_t count, uint32_t batch_seed, float *positions,
+                                  float *directions, hipStream_t stream);
 LaunchShape persistent_shape(int device);
 
 } // namespace ct

@@ -779,6 +779,99 @@ hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_
 }
 
 // =============================================================================================
+// scatter-sample generator: generatePoints + firstScatterPosition (dataset tooling, not hot)
+// =============================================================================================
+// getNextScatteringEvent (cloud.cuh:77-114) as a plain loop; returns true when the flight collided
+// and leaves the scatter position (or the exit position) in `pos`.
+CT_DEV bool plain_flight(const DevScene &sc, float xi, f3 &pos, f3 dir)
+{
+    const f3 stepv = scale3(dir, sc.sample_step);
+    float T = 1;
+    while (in_box(sc, pos)) {
+        pos = add3(pos, stepv);
+        const float density = tex3_apron(sc, sc.dbricks, pos) * sc.density_multiplier;
+        const float extinction = density * sc.sample_step;
+        T *= ct_expf(-extinction);
+        if (xi > T) {
+            const float lg = ct_logf(xi / T);
+            const float inv = 1.0f / density;
+            pos = sub3(pos, scale3(scale3(dir, lg), inv));
+            return true;
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void scatter_samples_kernel(DevScene sc, uint32_t count, uint32_t batch_seed,
+                                                            float *__restrict__ positions,
+                                                            float *__restrict__ directions)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) {
+        return;
+    }
+    uint32_t seed = tea4(i, batch_seed);
+    const float nanv = __uint_as_float(0x7fc00000u);
+    f3 out_p = mk3(nanv, nanv, nanv), out_d = mk3(nanv, nanv, nanv); // `clear`, pointGeneratorCamera.cu:44-48
+    for (uint32_t attempt = 0; attempt < 4096u; attempt++) {
+        // uniformOnSphere, random.cuh:133-148
+        const float u = u24_to_float(lcg24(seed));
+        const float v = u24_to_float(lcg24(seed));
+        const float phi = u * kPi * 2;
+        const float cos_theta = 2 * v - 1;
+        const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+        float sn, cs;
+        ct_sincosf(phi, &sn, &cs);
+        const f3 normal = mk3(cs * sin_theta, sn * sin_theta, cos_theta);
+        // uniformOnDisc(seed, normal), random.cuh:161-172: (x, 0, y) through Onb(normal)
+        const float theta = u24_to_float(lcg24(seed)) * kPi * 2;
+        const float sqrt_r = sqrtf(u24_to_float(lcg24(seed)));
+        float st, ct;
+        ct_sincosf(theta, &st, &ct);
+        const float dx = sqrt_r * ct, dy = sqrt_r * st;
+        f3 b;
+        if (fabsf(normal.x) > fabsf(normal.z)) {
+            b = mk3(-normal.y, normal.x, 0.0f);
+        } else {
+            b = mk3(0.0f, -normal.z, normal.y);
+        }
+        b = normalize3(b);
+        const f3 tg = cross3(b, normal);
+        const f3 disc = add3(add3(scale3(tg, dx), scale3(b, 0.0f)), scale3(normal, dy));
+        const float disc_radius = sqrtf(3.0f) / 2;
+        const f3 position = scale3(disc, disc_radius);
+        const f3 origin = add3(position, scale3(normal, 2.0f));
+        const f3 rdir = mk3(-normal.x, -normal.y, -normal.z);
+        float t_hit;
+        if (!intersect_box(sc, origin, rdir, t_hit)) {
+            continue; // the reference's miss program: nothing recorded, try again
+        }
+        // firstScatterPosition, cloudFirstScatterMaterial.cu:8-29
+        f3 pos = add3(origin, scale3(rdir, t_hit));
+        pos = add3(pos, scale3(mk3(sc.bx, sc.by, sc.bz), 0.5f));
+        const f3 direction = normalize3(rdir);
+        uint32_t seed2 = tea4(i * 4096u, batch_seed + attempt);
+        const float xi = u24_to_float(lcg24(seed2));
+        const bool scattered = plain_flight(sc, xi, pos, direction);
+        if (scattered && in_box(sc, pos)) {
+            out_p = sub3(pos, scale3(mk3(sc.bx, sc.by, sc.bz), 0.5f));
+            out_d = rdir;
+            break;
+        }
+    }
+    positions[3 * (size_t)i + 0] = out_p.x; positions[3 * (size_t)i + 1] = out_p.y; positions[3 * (size_t)i + 2] = out_p.z;
+    directions[3 * (size_t)i + 0] = out_d.x; directions[3 * (size_t)i + 1] = out_d.y; directions[3 * (size_t)i + 2] = out_d.z;
+}
+
+hipError_t launch_scatter_samples(const DevScene &sc, uint32_t count, uint32_t batch_seed, float *positions,
+                                  float *directions, hipStream_t stream)
+{
+    hipLaunchKernelGGL(scatter_samples_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, sc, count, batch_seed,
+                       positions, directions);
+    return hipGetLastError();
+}
+
+// =============================================================================================
 // progressive accumulation (progressive.cu:17-27) of S consecutive subframes, in order.
 // Only this shard's pixels are touched; everything else stays exactly 0 so that a sum over
 // shards (RCCL) reproduces the single-GPU image bit for bit.

@@ -219,6 +219,17 @@ typedef struct CtPointRadianceTask {
 CT_API int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_host, uint32_t count,
                                     uint32_t first_frame_id, uint32_t launches);
 
+/* generatePoints (src/CUDA/pointGeneratorCamera.cu:20-42) + firstScatterPosition
+ * (cloudFirstScatterMaterial.cu:8-29), launched over `count` threads by ScatterSampleCollector::collect
+ * (ScatterSampleCollector.cpp:36-62): thread i draws a direction uniformly on the sphere and a point on
+ * the reference's disc of radius sqrt(3)/2, shoots a ray from 2 units away and keeps the first scatter
+ * position (world coordinates, box centred at 0) and the view direction; it retries until a ray
+ * scatters inside the cloud (at most 4096 times, then the sample stays NaN like after `clear`).
+ * Seeds: tea<4>(i, batch_seed) for the generator and tea<4>(i*4096, batch_seed + attempt) for the
+ * flight (the reference mixes clock() into both).  Outputs are host arrays of 3*count floats. */
+CT_API int ct_generate_scatter_samples(CtHandle h, uint32_t count, uint32_t batch_seed,
+                                       float *positions_host_out, float *directions_host_out);
+
 /* ---- data access -------------------------------------------------------------------- */
 
 /* BufferBind<T>(buffer) map/copy, src/Util/BufferBind.h:11-74 (e.g. Camera.cpp:161,239-240).

@@ -508,6 +508,58 @@ ORC_API void orc_point_radiance(const OrcScene *s, uint32_t launch_id, uint32_t 
     }
 }
 
+/* generatePoints (pointGeneratorCamera.cu:20-42) with uniformOnSphere / uniformOnDisc
+ * (random.cuh:133-172) and firstScatterPosition (cloudFirstScatterMaterial.cu:8-29).  Seeds:
+ * tea<4>(i, batch_seed) and tea<4>(i*4096, batch_seed + attempt) (the reference mixes clock() in). */
+ORC_API void orc_generate_scatter_samples(const OrcScene *s, uint32_t count, uint32_t batch_seed,
+                                          float *positions, float *directions)
+{
+    Ctx c;
+    ctx_init(&c, s);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t ii = 0; ii < (int64_t)count; ii++) {
+        const uint32_t i = (uint32_t)ii;
+        OrcCounters k = { 0, 0, 0, 0, 0, 0 };
+        uint32_t seed = orc_tea4(i, batch_seed);
+        v3 out_p = v3_make(NAN, NAN, NAN), out_d = v3_make(NAN, NAN, NAN);
+        for (uint32_t attempt = 0; attempt < 4096u; attempt++) {
+            const float u = orc_rnd(&seed);
+            const float v = orc_rnd(&seed);
+            const float phi = u * ORC_PI_F * 2;
+            const float cos_theta = 2 * v - 1;
+            const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+            float sn, cs;
+            ct_sincosf(phi, &sn, &cs);
+            const v3 normal = v3_make(cs * sin_theta, sn * sin_theta, cos_theta);
+            const float theta = orc_rnd(&seed) * ORC_PI_F * 2;
+            const float sqrt_r = sqrtf(orc_rnd(&seed));
+            float st, ct;
+            ct_sincosf(theta, &st, &ct);
+            const v3 disc = onb_inverse_transform(normal, v3_make(sqrt_r * ct, 0.0f, sqrt_r * st));
+            const float disc_radius = sqrtf(3.0f) / 2;
+            const v3 position = v3_scale(disc, disc_radius);
+            const v3 origin = v3_add(position, v3_scale(normal, 2.0f));
+            const v3 rdir = v3_neg(normal);
+            float t_hit;
+            if (!intersect_box(&c, origin, rdir, &t_hit)) {
+                continue;
+            }
+            v3 pos = v3_add(origin, v3_scale(rdir, t_hit));
+            pos = v3_add(pos, v3_scale(c.bbox, 0.5f));
+            const v3 direction = v3_normalize(rdir);
+            uint32_t seed2 = orc_tea4(i * 4096u, batch_seed + attempt);
+            const Event e = next_scattering_event(&c, orc_rnd(&seed2), pos, direction, &k);
+            if (in_box(&c, e.pos) && e.scattered) {
+                out_p = v3_sub(e.pos, v3_scale(c.bbox, 0.5f));
+                out_d = rdir;
+                break;
+            }
+        }
+        positions[3 * (size_t)i + 0] = out_p.x; positions[3 * (size_t)i + 1] = out_p.y; positions[3 * (size_t)i + 2] = out_p.z;
+        directions[3 * (size_t)i + 0] = out_d.x; directions[3 * (size_t)i + 1] = out_d.y; directions[3 * (size_t)i + 2] = out_d.z;
+    }
+}
+
 /* Gpu::PointRadianceTask (src/CUDA/PointRadianceTask.h:12-78), 40 bytes. */
 typedef struct OrcPointTask {
     int32_t id;

@@ -115,6 +115,7 @@ def lib(fast: bool = False):
     L.orc_inscatter.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_int32]
     L.orc_point_radiance_launch.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.POINTER(OrcCounters), C.c_int32]
+    L.orc_generate_scatter_samples.argtypes = [C.POINTER(OrcScene), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.orc_point_task_merge.restype = C.c_int32
     L.orc_point_task_merge.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_camera_variables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
@@ -259,6 +260,12 @@ class Oracle:
                 frame[~mask] = 0
             self.L.orc_accumulate(_ptr(frame), _ptr(mean), _ptr(m2), sid, self.width * self.height)
         return mean, m2
+
+    def generate_scatter_samples(self, count: int, batch_seed: int = 0):
+        pos = np.empty((count, 3), np.float32)
+        d = np.empty((count, 3), np.float32)
+        self.L.orc_generate_scatter_samples(C.byref(self.scene), count, batch_seed, _ptr(pos), _ptr(d))
+        return pos, d
 
     def point_radiance_launch(self, tasks: np.ndarray, first_frame: int, launches: int) -> np.ndarray:
         """Oracle twin of ct_point_radiance_launch; `tasks` has the 40-byte PointRadianceTask layout."""

@@ -145,3 +145,40 @@ def test_collector_end_to_end_on_gpu(tmp_path):
     table, recs = col.read_flat_dataset(tmp_path / "res.flat")
     assert table == "Result" and len(recs) == c.get_converged_count()
     tr.close()
+
+
+def test_scatter_sample_generator_oracle_properties():
+    """The generated points are first-scatter positions inside the cloud and the view directions
+    are unit vectors (pointGeneratorCamera.cu:20-42)."""
+    tex = sphere_volume(24, seed=3)
+    orc = O.Oracle(tex, 8, 8, mode=1, fast=True)
+    pos, d = orc.generate_scatter_samples(200, batch_seed=5)
+    assert np.isfinite(pos).all() and np.isfinite(d).all()
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5)
+    assert np.all(np.abs(pos) <= 0.51)                              # world coordinates, box centred at 0
+    # a first-scatter position sits where the density is non-zero (trilinear footprint)
+    dens = [O.tex3d(tex, p + 0.5) for p in pos]
+    assert min(dens) > 0
+    pos2, d2 = orc.generate_scatter_samples(200, batch_seed=5)
+    assert np.array_equal(pos, pos2) and np.array_equal(d, d2)
+    pos3, _ = orc.generate_scatter_samples(200, batch_seed=6)
+    assert not np.array_equal(pos, pos3)
+
+
+@pytest.mark.gpu
+def test_scatter_sample_generator_bit_exact_on_gpu():
+    tex = sphere_volume(32, seed=13)
+    tr = ds.CloudTracer(tex, width=8, height=8, mode=1)
+    orc = O.Oracle(tex, 8, 8, mode=1, fast=True)
+    for seed in (0, 77):
+        gp, gd = tr.generate_scatter_samples(300, seed)
+        rp, rd = orc.generate_scatter_samples(300, seed)
+        assert np.array_equal(gp, rp) and np.array_equal(gd, rd)
+    # generator -> collector -> records: the whole dataset path of Tasks::collect
+    gp, gd = tr.generate_scatter_samples(64, 1)
+    c = col.RadianceCollector(tr.point_radiance_launch, gp, gd, max_thread_count=1024, launches_per_update=50)
+    c.update()
+    assert c.frame_id == 50
+    recs = [(i, col.encode_scatter_sample(3, gp[i], gd[i])) for i in range(len(gp))]
+    assert col.decode_scatter_sample(recs[5][1])[0] == 3
+    tr.close()

@@ -43,6 +43,9 @@ def parse_args():
                     help="subframes per progressive batch (one estimator launch + one accumulate launch); "
                          "default 64 x n_gpus, i.e. a constant number of samples per GPU per launch")
     ap.add_argument("--mode", type=int, default=0, help="0 totalRadiance (Mie multi-scatter + NEE)")
+    ap.add_argument("--estimator", type=int, default=0, choices=(0, 1),
+                    help="0 MARCH = the reference's free-flight sampler (the parity path, default); "
+                         "1 DELTA = Woodcock tracking over brick majorants (unbiased, not the reference's)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--simple-kernel", action="store_true", help="A/B: one thread per pixel, nested loops")
@@ -117,7 +120,7 @@ def main():
     tex = ds.make_procedural_cloud(args.volume)
     flags = _lib.CT_FLAG_SIMPLE_KERNEL if args.simple_kernel else 0
     from deepestscatter_amd.distributed import ShardedTracer
-    st = ShardedTracer(tex, ds.SceneParams(width=W, height=H, mode=args.mode, flags=flags), rank, world, local_rank)
+    st = ShardedTracer(tex, ds.SceneParams(width=W, height=H, mode=args.mode, estimator=args.estimator, flags=flags), rank, world, local_rank)
     tr = st.tracer
     setup_s = time.perf_counter() - t_setup
 
@@ -169,7 +172,7 @@ def main():
     # calibration and the launch configuration it is valid for.
     traffic = None
     pmc = ROOT / "profiles" / "pmc_latest.json"
-    if pmc.exists() and world == 1 and not args.simple_kernel:
+    if pmc.exists() and world == 1 and not args.simple_kernel and args.estimator == 0:
         try:
             rec = json.loads(pmc.read_text())
             lc = rec.get("launch_config", {})
@@ -178,7 +181,8 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": "render_persistent_kernel" if not args.simple_kernel else "render_simple_kernel",
+        "bound": "hbm",
+        "kernel": "render_simple_kernel" if args.simple_kernel else ("render_delta_kernel" if args.estimator else "render_persistent_kernel"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
         "algorithmic_bytes_per_launch": alg_bytes / launches,
@@ -200,7 +204,8 @@ def main():
             "workload": f"{args.volume}^3 procedural density, {W}x{H}, progressive, {S} spp per step "
                         f"(BASELINE.json configs[{2 if world == 1 else 3}]: 1024 spp job = {max(1024 // max(S, 1), 1)} such steps), "
                         f"mode {('totalRadiance','multipleScatterSunRadiance','singleScatterSunRadiance')[args.mode]} "
-                        "(Mie multi-scatter + NEE), estimator MARCH (reference-faithful), max_depth 2000",
+                        "(Mie multi-scatter + NEE), estimator "
+                        f"{('MARCH (reference-faithful)', 'DELTA (Woodcock, brick majorants)')[args.estimator]}, max_depth 2000",
             "volume": args.volume, "width": W, "height": H, "spp_per_step": S,
             "parallelism": f"pixel-tile shard x{world}" + (" + RCCL reduce of the radiance buffer" if world > 1 else ""),
         },

@@ -31,7 +31,7 @@ struct CtHandle_ {
     bool camera_set = false;
 
     // device memory
-    uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr;
+    uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr, *d_majorant = nullptr;
     uint8_t *d_dbricks = nullptr, *d_ibricks = nullptr;
     float *d_mie = nullptr, *d_chopped = nullptr, *d_cdf = nullptr;
     uint16_t *d_guide = nullptr;
@@ -187,7 +187,7 @@ static void release(CtHandle h)
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_primary, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_primary, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
         if (p) {
@@ -307,6 +307,8 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.brick_bias = bbias;
     d.brick_gx = (int32_t)bgx;
     d.brick_gxy = (int32_t)(bgx * bgy);
+    d.brick_gy = (int32_t)bgy;
+    d.brick_gz = (int32_t)bgz;
     const size_t brick_bytes = (size_t)(bgx * bgy * bgz) * 128;
 
     // ---- Mie textures (Mie.cpp:8206-8297) + guide table
@@ -345,9 +347,11 @@ static int create_impl(const CtScene *s, CtHandle h)
         const size_t nb = (size_t)(bgx * bgy * bgz);
         HIPCHK(h, dmalloc(&h->d_dist, nb));
         HIPCHK(h, dmalloc(&h->d_dist_tmp, nb));
+        HIPCHK(h, dmalloc(&h->d_majorant, nb));
         HIPCHK(h, launch_build_dist(h->d_density, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_dist,
-                                    h->d_dist_tmp, h->stream));
-        HIPCHK(h, launch_brick_meta(h->d_dist, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_dbricks, h->stream));
+                                    h->d_dist_tmp, h->d_majorant, h->stream));
+        HIPCHK(h, launch_brick_meta(h->d_dist, h->d_majorant, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz,
+                                    h->d_dbricks, h->stream));
     }
     HIPCHK(h, launch_inscatter(d, h->d_inscatter, h->stream));
     HIPCHK(h, launch_build_bricks(h->d_inscatter, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_ibricks, h->stream));
@@ -397,8 +401,11 @@ extern "C" int ct_create(const CtScene *s, CtHandle *out)
     if (s->mode < 0 || s->mode > 2) {
         return fail(nullptr, CT_E_INVAL, "Invalid Render Mode %d", s->mode); // CloudMaterial.cpp:62
     }
-    if (s->estimator != CT_EST_MARCH) {
-        return fail(nullptr, CT_E_INVAL, "estimator %d not available in this build", s->estimator);
+    if (s->estimator != CT_EST_MARCH && s->estimator != CT_EST_DELTA) {
+        return fail(nullptr, CT_E_INVAL, "unknown estimator %d", s->estimator);
+    }
+    if (s->estimator == CT_EST_DELTA && (s->flags & CT_FLAG_SIMPLE_KERNEL)) {
+        return fail(nullptr, CT_E_INVAL, "the one-thread-per-pixel cross-check kernel only implements MARCH");
     }
     if (!s->mie_host || !s->chopped_mie_host || s->mie_count != (uint32_t)kMieN) {
         return fail(nullptr, CT_E_INVAL, "Mie tables must be %d floats each", kMieN);
@@ -674,7 +681,7 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
     ba.pixels = h->d_pixels;
     ba.job_group = h->d_job_group;
     ba.job_sub = h->d_job_sub;
-    ba.cost = h->d_cost;
+    ba.cost = h->order_tuned ? nullptr : h->d_cost;
     ba.n_jobs = h->n_jobs;
     ba.first_subframe = first;
     ba.S = S;
@@ -693,7 +700,11 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
         }
     } else {
         if (h->n_jobs != 0) {
-            HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+            if (h->scene.estimator == CT_EST_DELTA) {
+                HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
+            } else {
+                HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+            }
         }
         h->host_paths += h->own_pixels * S;
         h->host_hits += h->hit_pixels * S;
@@ -861,7 +872,7 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         ba.pixels = d_pixels;
         ba.job_group = d_jg;
         ba.job_sub = d_js;
-        ba.cost = d_cost;
+        ba.cost = nullptr;
         ba.n_jobs = (uint32_t)jg.size();
         ba.first_subframe = first_frame_id;
         ba.S = launches;
@@ -869,7 +880,11 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         ba.counters = h->d_counters;
         ba.stats = h->d_counters + kCounterCount + 1;
         HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-        HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+        if (h->scene.estimator == CT_EST_DELTA) {
+            HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
+        } else {
+            HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+        }
         HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
         HIPCHK(h, launch_point_accumulate(d_frames, n_pad, d_tasks, count, launches, h->stream));
         HIPCHK(h, hipMemcpyAsync(tasks_host, d_tasks, (size_t)count * sizeof(CtPointRadianceTask),

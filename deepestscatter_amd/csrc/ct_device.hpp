@@ -60,11 +60,13 @@ struct DevScene {
     int32_t brick_bias;      // added to a texel index to make it non-negative (multiple of 4)
     int32_t brick_gx;        // bricks per row
     int32_t brick_gxy;       // bricks per slice
-    // Byte 125 of every DENSITY brick is its meta byte: bits 0-6 = free-space distance D
-    // (Chebyshev distance, in bricks, capped, to the nearest brick that is not provably "free":
-    // all texels a trilinear footprint based in it can touch are zero), bit 7 = "interior" (every
-    // position whose base texel lies in the brick passes isInBox, and so does a scatter position
-    // backed off from it).  It rides in the cache line the footprint is read from.
+    int32_t brick_gy, brick_gz;
+    // Bytes 125 and 126 of every DENSITY brick are its meta bytes.  Byte 126 = majorant M: the
+    // max of the texels [lo-1, lo+5]^3, i.e. of everything a trilinear footprint based in the brick
+    // (or on its boundary) can read.  Byte 125: bits 0-6 = free-space distance D (Chebyshev
+    // distance, in bricks, capped, to the nearest brick that is not "free" = M == 0 and interior),
+    // bit 7 = "interior" (every position whose base texel lies in the brick passes isInBox, and so
+    // does a scatter position backed off from it).  They ride in the footprint's cache line.
     int32_t nx, ny, nz;    // texels
     float sx, sy, sz;      // box coordinate -> texel coordinate (textureScale * N)
     float bx, by, bz;      // bboxSize          (VDBCloud.cpp:104)
@@ -314,8 +316,8 @@ CT_DEV bool intersect_box(const DevScene &sc, f3 o, f3 d, float &t_hit)
     return false;
 }
 
-// ---- log for the march's back-off: the argument xi/T is > 1 and finite (xi > T > 0), so ct_logf's
-// special cases (<= 0, inf, subnormal) can never fire; same instruction sequence otherwise. -----
+// ---- log of a positive NORMAL float (the march's xi/T > 1, the delta tracker's 1-u >= 2^-24):
+// ct_logf's special cases (<= 0, inf, subnormal) can never fire; same instruction sequence otherwise.
 CT_DEV float logf_above_one(float x)
 {
     const uint32_t u = ct_float_to_bits(x);

@@ -27,7 +27,8 @@ struct BatchArgs {
     // every wave still stays on one 64-pixel group at a time (cache locality).
     const uint32_t *job_group;
     const uint32_t *job_sub;
-    uint32_t *cost;            // per group: sum of path depths, feeds the next job list
+    uint32_t *cost;            // per group: sum of path depths, feeds the next job list; NULL once
+                               // the order is tuned (hundreds of waves share a group at large S)
     uint32_t n_jobs;
     uint32_t first_subframe;   // 1-based subframeId of slice 0
     uint32_t S;
@@ -50,9 +51,10 @@ __host__ __device__ inline uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_
 hipError_t launch_build_bricks(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
                                uint8_t *bricks, hipStream_t stream);
 hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
-                             uint8_t *dist, uint8_t *scratch, hipStream_t stream);
-hipError_t launch_brick_meta(const uint8_t *dist, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
-                             uint8_t *bricks, hipStream_t stream);
+                             uint8_t *dist, uint8_t *scratch, uint8_t *majorant, hipStream_t stream);
+hipError_t launch_brick_meta(const uint8_t *dist, const uint8_t *majorant, int nx, int ny, int nz, int bias, int gx,
+                             int gy, int gz, uint8_t *bricks, hipStream_t stream);
+hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream);
 hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream);
 hipError_t launch_fill_frame(float4 *frame, uint32_t width, uint32_t height, uint32_t shard_index,

@@ -60,11 +60,11 @@ hipError_t launch_build_bricks(const uint8_t *texels, int nx, int ny, int nz, in
 // =============================================================================================
 constexpr int kDistMax = 64;
 
-// dist = kDistMax for free bricks, 0 otherwise.  A brick is free when every texel a trilinear
-// footprint based inside it can read ([lo-1, hi+1]^3) is zero and its texel range lies in
-// [1, N-3] on every axis, which implies isInBox for every position whose base texel is in it.
+// Majorant of every brick (see DevScene) and the seed of the distance transform: dist = kDistMax
+// for free bricks (majorant 0 and texel range inside [1, N-3] on every axis, which implies isInBox
+// for every position whose base texel is in the brick), 0 otherwise.
 __global__ void brick_free_kernel(const uint8_t *__restrict__ t, int nx, int ny, int nz, int bias, int gx, int gy,
-                                  int gz, uint8_t *__restrict__ dist)
+                                  int gz, uint8_t *__restrict__ dist, uint8_t *__restrict__ majorant)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= gx * gy * gz) {
@@ -72,27 +72,25 @@ __global__ void brick_free_kernel(const uint8_t *__restrict__ t, int nx, int ny,
     }
     const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
     const int x0 = bx * kBrick - bias, y0 = by * kBrick - bias, z0 = bz * kBrick - bias;
-    bool free_ = x0 >= 1 && y0 >= 1 && z0 >= 1 && x0 + kBrick - 1 <= nx - 3 && y0 + kBrick - 1 <= ny - 3 &&
-                 z0 + kBrick - 1 <= nz - 3;
-    if (free_) {
-        for (int z = z0 - 1; z <= z0 + kBrick && free_; z++) {
-            for (int y = y0 - 1; y <= y0 + kBrick && free_; y++) {
-                const uint8_t *row = t + ((size_t)z * ny + y) * nx;
-                for (int x = x0 - 1; x <= x0 + kBrick; x++) {
-                    if (row[x] != 0) {
-                        free_ = false;
-                        break;
-                    }
-                }
+    const bool interior = x0 >= 1 && y0 >= 1 && z0 >= 1 && x0 + kBrick - 1 <= nx - 3 && y0 + kBrick - 1 <= ny - 3 &&
+                          z0 + kBrick - 1 <= nz - 3;
+    int m = 0;
+    for (int z = z0 - 1; z <= z0 + kBrick + 1; z++) {
+        const int zc = min(max(z, 0), nz - 1);
+        for (int y = y0 - 1; y <= y0 + kBrick + 1; y++) {
+            const uint8_t *row = t + ((size_t)zc * ny + min(max(y, 0), ny - 1)) * nx;
+            for (int x = x0 - 1; x <= x0 + kBrick + 1; x++) {
+                m = max(m, (int)row[min(max(x, 0), nx - 1)]);
             }
         }
     }
-    dist[b] = free_ ? (uint8_t)kDistMax : (uint8_t)0;
+    majorant[b] = (uint8_t)m;
+    dist[b] = (interior && m == 0) ? (uint8_t)kDistMax : (uint8_t)0;
 }
 
 // Writes the meta byte (see DevScene) into byte 125 of every density brick.
-__global__ void brick_meta_kernel(const uint8_t *__restrict__ dist, int nx, int ny, int nz, int bias, int gx, int gy,
-                                  int gz, uint8_t *__restrict__ bricks)
+__global__ void brick_meta_kernel(const uint8_t *__restrict__ dist, const uint8_t *__restrict__ majorant, int nx,
+                                  int ny, int nz, int bias, int gx, int gy, int gz, uint8_t *__restrict__ bricks)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= gx * gy * gz) {
@@ -103,6 +101,7 @@ __global__ void brick_meta_kernel(const uint8_t *__restrict__ dist, int nx, int 
     const bool interior = x0 >= 1 && y0 >= 1 && z0 >= 1 && x0 + kBrick - 1 <= nx - 3 && y0 + kBrick - 1 <= ny - 3 &&
                           z0 + kBrick - 1 <= nz - 3;
     bricks[((size_t)b << 7) + 125] = (uint8_t)(min((int)dist[b], 127) | (interior ? 0x80 : 0));
+    bricks[((size_t)b << 7) + 126] = majorant[b];
 }
 
 // One relaxation of the Chebyshev distance transform: d = min(d, 1 + min over the 26 neighbours).
@@ -130,12 +129,12 @@ __global__ void brick_dist_relax_kernel(const uint8_t *__restrict__ in, uint8_t 
 }
 
 hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
-                             uint8_t *dist, uint8_t *scratch, hipStream_t stream)
+                             uint8_t *dist, uint8_t *scratch, uint8_t *majorant, hipStream_t stream)
 {
     const int total = gx * gy * gz;
     const int threads = 256, blocks = (total + threads - 1) / threads;
     hipLaunchKernelGGL(brick_free_kernel, dim3(blocks), dim3(threads), 0, stream, texels, nx, ny, nz, bias, gx, gy,
-                       gz, dist);
+                       gz, dist, majorant);
     // kDistMax relaxations make every value exact up to the cap; ping-pong, ending in `dist`
     uint8_t *a = dist, *b = scratch;
     for (int i = 0; i < kDistMax; i++) {
@@ -153,12 +152,12 @@ hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int 
     return hipGetLastError();
 }
 
-hipError_t launch_brick_meta(const uint8_t *dist, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
-                             uint8_t *bricks, hipStream_t stream)
+hipError_t launch_brick_meta(const uint8_t *dist, const uint8_t *majorant, int nx, int ny, int nz, int bias, int gx,
+                             int gy, int gz, uint8_t *bricks, hipStream_t stream)
 {
     const int total = gx * gy * gz;
-    hipLaunchKernelGGL(brick_meta_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, dist, nx, ny, nz, bias, gx,
-                       gy, gz, bricks);
+    hipLaunchKernelGGL(brick_meta_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, dist, majorant, nx, ny, nz,
+                       bias, gx, gy, gz, bricks);
     return hipGetLastError();
 }
 
@@ -594,7 +593,9 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         }
         if (finished) {
             ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
-            atomicAdd(&ba.cost[group], depth);
+            if (ba.cost) {
+                atomicAdd(&ba.cost[group], depth);
+            }
             state = ST_IDLE;
         }
     }
@@ -639,6 +640,340 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         atomicAdd(&ba.counters[4], (unsigned long long)vals[1]); // scatter events == NEE lookups
         atomicAdd(&ba.counters[5], (unsigned long long)vals[2]);
     }
+}
+
+// =============================================================================================
+// DELTA estimator: Woodcock tracking over the brick majorants (BASELINE.json north_star; not the
+// reference's sampler -- the oracle twin is delta_flight() in oracle/ct_oracle.c, whose header
+// states the algorithm).  Same persistent wave scheduler; the "march" phase becomes one tracking
+// visit per lane with exactly one dependent load:
+//     current brick empty (M == 0)  -> cross max(D-1, 1) bricks by replaying the DDA steps (every
+//                                      brick within Chebyshev distance D-1 is free, so the oracle's
+//                                      plain DDA finds M == 0 in each and does the same arithmetic),
+//                                      then load the meta bytes of the brick reached;
+//     M > 0                          -> draw dt = -log(1-u)/sigma_bar; if it leaves the brick, cross
+//                                      one brick and load its meta bytes; otherwise advance, load the
+//                                      footprint at p = fma(dir, t, origin) and accept the collision
+//                                      when u' * sigma_bar < sigma(p).
+// =============================================================================================
+struct Dda {
+    f3 org;            // origin of the flight (box coordinates), positions are fma(dir, t, org)
+    float t;
+    f3 tmax, tdelta;   // ray parameter at the next brick boundary per axis / between boundaries
+    int32_t bx, by, bz;
+    uint32_t meta;     // meta bytes of the brick (bx,by,bz): D | interior << 7 | M << 8
+};
+
+CT_DEV uint32_t load_brick_meta(const DevScene &sc, int32_t bx, int32_t by, int32_t bz)
+{
+    const uint32_t brick = __umul24((uint32_t)bz, (uint32_t)sc.brick_gxy) + __umul24((uint32_t)by, (uint32_t)sc.brick_gx) + (uint32_t)bx;
+    const uint8_t *p = sc.dbricks + ((size_t)brick << 7) + 125;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8);
+}
+
+CT_DEV bool brick_in_grid(const DevScene &sc, const Dda &d)
+{
+    return d.bx >= 0 && d.by >= 0 && d.bz >= 0 && d.bx < sc.brick_gx && d.by < sc.brick_gy && d.bz < sc.brick_gz;
+}
+
+// DDA set-up of a flight from `pos` along `dir`; leaves the meta load in flight.
+CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
+{
+    d.org = pos;
+    d.t = 0.0f;
+    const float tpx = fmaf(pos.x, sc.sx, -0.5f), tpy = fmaf(pos.y, sc.sy, -0.5f), tpz = fmaf(pos.z, sc.sz, -0.5f);
+    const float vx = dir.x * sc.sx, vy = dir.y * sc.sy, vz = dir.z * sc.sz;
+    d.bx = (floor_to_int(tpx) + sc.brick_bias) >> 2;
+    d.by = (floor_to_int(tpy) + sc.brick_bias) >> 2;
+    d.bz = (floor_to_int(tpz) + sc.brick_bias) >> 2;
+    const float inf = __uint_as_float(0x7f800000u);
+    auto axis = [&](int32_t B, float TP, float V, float &TMAX, float &TDELTA) {
+        if (V > 0.0f) {
+            TMAX = ((float)(((B + 1) << 2) - sc.brick_bias) - TP) / V;
+            TDELTA = 4.0f / V;
+        } else if (V < 0.0f) {
+            TMAX = ((float)((B << 2) - sc.brick_bias) - TP) / V;
+            TDELTA = 4.0f / -V;
+        } else {
+            TMAX = inf;
+            TDELTA = inf;
+        }
+    };
+    axis(d.bx, tpx, vx, d.tmax.x, d.tdelta.x);
+    axis(d.by, tpy, vy, d.tmax.y, d.tdelta.y);
+    axis(d.bz, tpz, vz, d.tmax.z, d.tdelta.z);
+    d.meta = brick_in_grid(sc, d) ? load_brick_meta(sc, d.bx, d.by, d.bz) : 0u;
+}
+
+// One brick crossing: t = exit parameter, step along the axis with the smallest tmax
+// (ties: x before y before z), exactly like the oracle.
+CT_DEV void dda_cross(Dda &d, f3 dir)
+{
+    const float t_exit = fminf(fminf(d.tmax.x, d.tmax.y), d.tmax.z);
+    d.t = t_exit;
+    if (d.tmax.x <= d.tmax.y && d.tmax.x <= d.tmax.z) {
+        d.bx += (dir.x > 0.0f) ? 1 : -1;
+        d.tmax.x += d.tdelta.x;
+    } else if (d.tmax.y <= d.tmax.z) {
+        d.by += (dir.y > 0.0f) ? 1 : -1;
+        d.tmax.y += d.tdelta.y;
+    } else {
+        d.bz += (dir.z > 0.0f) ? 1 : -1;
+        d.tmax.z += d.tdelta.z;
+    }
+}
+
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArgs ba)
+{
+    __shared__ MieLds lds;
+    load_tables(sc, lds);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), rad = mk3(0, 0, 0);
+    Dda dda{};
+    uint32_t seed = 0, depth = 0, out_idx = 0, group = 0;
+    int state = ST_IDLE;
+
+    uint32_t q_next = 0, q_end = 0, job_g = 0, job_s0 = 0;
+    bool drained = false;
+    uint32_t c_dl = 0, c_il = 0, c_cap = 0;
+    uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
+    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0;
+
+    for (;;) {
+        // ---------------- regenerate ----------------
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if ((n_idle >= sc.regen_min || n_idle == 64u) && !(drained && q_next == q_end)) {
+            if (q_next == q_end) {
+                uint32_t j = 0;
+                if (lane == 0) {
+                    j = atomicAdd(ba.queue, 1u);
+                }
+                j = __builtin_amdgcn_readfirstlane(j);
+                if (j >= ba.n_jobs) {
+                    drained = true;
+                } else {
+                    const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
+                    job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
+                    job_s0 = sub & 0xffffu;
+                    q_next = 0;
+                    q_end = (sub >> 16) * 64u;
+                }
+            }
+            if (q_next != q_end) {
+                const uint32_t avail = q_end - q_next;
+                if (STATS) {
+                    st_regen += 1;
+                    st_regen_l += min(n_idle, avail);
+                }
+                const uint32_t rank = lane_rank(idle);
+                const bool take = (state == ST_IDLE) && rank < avail;
+                const uint32_t q = q_next + rank;
+                q_next += min(n_idle, avail);
+                if (take) {
+                    const uint32_t s = job_s0 + (q >> 6), l = q & 63u;
+                    const uint32_t g = job_g;
+                    const uint32_t pixel = ba.pixels[g * 64u + l];
+                    if (pixel != 0xffffffffu) {
+                        const float4 p0 = ba.primary[2 * (size_t)pixel];
+                        const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
+                        out_idx = ba.frame_stride ? s * ba.frame_stride + (g * 64u + l) : pixel;
+                        group = g;
+                        pos = mk3(p0.x, p0.y, p0.z);
+                        const bool hit = p0.w != 0.f;
+                        dir = mk3(p1.x, p1.y, p1.z);
+                        seed = tea4(__float_as_uint(p1.w), ba.first_subframe + s);
+                        rad = mk3(0, 0, 0);
+                        depth = 0;
+                        if (MODE == 1) {
+                            dir = new_direction(lds.cdf, lds.guide, seed, dir);
+                        }
+                        bool go = hit && in_box(sc, pos);
+                        if (MODE != 2 && go) {
+                            depth = 1;
+                            if (depth == sc.max_depth) {
+                                c_cap += 1;
+                                go = false;
+                            }
+                        }
+                        if (go) {
+                            dda_begin(sc, dda, pos, dir);
+                            state = ST_MARCH;
+                        } else {
+                            ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
+                        }
+                    }
+                }
+            }
+        }
+
+        const uint64_t marching = __builtin_amdgcn_ballot_w64(state == ST_MARCH);
+        const uint64_t bouncing = __builtin_amdgcn_ballot_w64(state == ST_BOUNCE);
+        const uint32_t nm = (uint32_t)__builtin_popcountll(marching);
+        const uint32_t nb = (uint32_t)__builtin_popcountll(bouncing);
+        if ((marching | bouncing) == 0) {
+            if (drained && q_next == q_end) {
+                break;
+            }
+            continue;
+        }
+
+        bool finished = false;
+        if (nb != 0) {
+            // ---------------- scatter (eager) ----------------
+            if (STATS) {
+                st_scat += 1;
+                st_scat_l += nb;
+            }
+            if (state == ST_BOUNCE) {
+                const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
+                rad = add3(rad, in_scattering(sc, pos, dir, chopped));
+                c_il += 1;
+                bool go = (MODE != 2);
+                if (go) {
+                    dir = new_direction(lds.cdf, lds.guide, seed, dir);
+                    depth++;
+                    if (depth == sc.max_depth) {
+                        c_cap += 1;
+                        go = false;
+                    }
+                }
+                if (go) {
+                    dda_begin(sc, dda, pos, dir);
+                    state = ST_MARCH;
+                } else {
+                    finished = true;
+                }
+            }
+        } else {
+            // ---------------- one tracking visit ----------------
+            if (STATS) {
+                st_march += 1;
+                st_march_l += nm;
+            }
+            if (state == ST_MARCH) {
+                if (!brick_in_grid(sc, dda)) {
+                    finished = true; // left the grid without a collision
+                } else {
+                    const uint32_t M = dda.meta >> 8;
+                    bool crossed = false;
+                    if (M == 0u) {
+                        const uint32_t D = dda.meta & 0x7fu;
+                        const uint32_t n = D > 1u ? D - 1u : 1u;
+                        for (uint32_t i = 0; i < n; i++) {
+                            dda_cross(dda, dir);
+                        }
+                        if (STATS) {
+                            st_skip += n;
+                        }
+                        crossed = true;
+                    } else {
+                        const float sigma_bar = ((float)M * (1.0f / 255.0f)) * sc.density_multiplier;
+                        const float u = u24_to_float(lcg24(seed));
+                        const float dt = -logf_above_one(1.0f - u) / sigma_bar;
+                        const float t_exit = fminf(fminf(dda.tmax.x, dda.tmax.y), dda.tmax.z);
+                        if (dda.t + dt >= t_exit) {
+                            dda_cross(dda, dir);
+                            crossed = true;
+                        } else {
+                            dda.t = dda.t + dt;
+                            const f3 p = mk3(fmaf(dir.x, dda.t, dda.org.x), fmaf(dir.y, dda.t, dda.org.y),
+                                             fmaf(dir.z, dda.t, dda.org.z));
+                            uint32_t meta_unused;
+                            const uint2 cell = fetch_cell(sc, sc.dbricks, p, meta_unused);
+                            c_dl += 1;
+                            if (STATS) {
+                                st_fetch += 1;
+                                st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
+                            }
+                            const float sigma = filter_at(sc, cell, p) * sc.density_multiplier;
+                            const float z = u24_to_float(lcg24(seed));
+                            if (z * sigma_bar < sigma) {
+                                pos = p;
+                                if (in_box(sc, pos)) {
+                                    state = ST_BOUNCE;
+                                } else {
+                                    finished = true;
+                                }
+                            }
+                        }
+                    }
+                    if (crossed) {
+                        dda.meta = brick_in_grid(sc, dda) ? load_brick_meta(sc, dda.bx, dda.by, dda.bz) : 0u;
+                    }
+                }
+            }
+        }
+        if (finished) {
+            ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+            if (ba.cost) {
+                atomicAdd(&ba.cost[group], depth);
+            }
+            state = ST_IDLE;
+        }
+    }
+
+    uint32_t vals[3] = { c_dl, c_il, c_cap };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        uint32_t v = vals[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            v += __shfl_xor(v, off);
+        }
+        vals[i] = v;
+    }
+    if (STATS) {
+        uint32_t sv[3] = { st_fetch, st_zero, st_skip };
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            uint32_t v = sv[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                v += __shfl_xor(v, off);
+            }
+            sv[i] = v;
+        }
+        if (lane == 0) {
+            atomicAdd(&ba.stats[0], (unsigned long long)st_regen);
+            atomicAdd(&ba.stats[1], (unsigned long long)st_regen_l);
+            atomicAdd(&ba.stats[2], (unsigned long long)st_march);
+            atomicAdd(&ba.stats[3], (unsigned long long)st_march_l);
+            atomicAdd(&ba.stats[4], (unsigned long long)st_scat);
+            atomicAdd(&ba.stats[5], (unsigned long long)st_scat_l);
+            atomicAdd(&ba.stats[6], (unsigned long long)sv[0]);
+            atomicAdd(&ba.stats[7], (unsigned long long)sv[1]);
+            atomicAdd(&ba.stats[8], (unsigned long long)sv[2]);
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&ba.counters[2], (unsigned long long)vals[0]);
+        atomicAdd(&ba.counters[3], (unsigned long long)vals[1]);
+        atomicAdd(&ba.counters[4], (unsigned long long)vals[1]);
+        atomicAdd(&ba.counters[5], (unsigned long long)vals[2]);
+    }
+}
+
+hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream)
+{
+    const dim3 grid(shape.blocks), block(shape.threads);
+    static const bool stats = getenv("CT_STATS") != nullptr;
+    if (stats) {
+        switch (sc.mode) {
+        case 0: hipLaunchKernelGGL((render_delta_kernel<0, true>), grid, block, 0, stream, sc, ba); break;
+        case 1: hipLaunchKernelGGL((render_delta_kernel<1, true>), grid, block, 0, stream, sc, ba); break;
+        default: hipLaunchKernelGGL((render_delta_kernel<2, true>), grid, block, 0, stream, sc, ba); break;
+        }
+    } else {
+        switch (sc.mode) {
+        case 0: hipLaunchKernelGGL((render_delta_kernel<0, false>), grid, block, 0, stream, sc, ba); break;
+        case 1: hipLaunchKernelGGL((render_delta_kernel<1, false>), grid, block, 0, stream, sc, ba); break;
+        default: hipLaunchKernelGGL((render_delta_kernel<2, false>), grid, block, 0, stream, sc, ba); break;
+        }
+    }
+    return hipGetLastError();
 }
 
 LaunchShape persistent_shape(int device)

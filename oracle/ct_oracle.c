@@ -198,6 +198,11 @@ typedef struct OrcScene {
     const float *chopped_mie_tex;  /* orc_mie_phase_texture(choppedMie) */
     const float *chopped_cdf_tex;  /* orc_mie_integral_texture(choppedMie) */
     uint32_t mie_count;
+    /* free-flight sampler: 0 = MARCH (the reference's, cloud.cuh:77-114), 1 = DELTA (Woodcock tracking
+     * over per-brick majorants; NOT in the reference -- BASELINE.json north_star / SURVEY section 7.6) */
+    int32_t estimator;
+    const uint8_t *majorant;       /* orc_build_majorants(), needed for DELTA */
+    int32_t maj_bias, maj_gx, maj_gy, maj_gz;
 } OrcScene;
 
 typedef struct OrcCounters {
@@ -220,6 +225,9 @@ typedef struct {
     uint32_t mie_n;
     uint32_t max_depth;
     int32_t mode;
+    int32_t estimator;
+    const uint8_t *maj;
+    int32_t maj_bias, maj_gx, maj_gy, maj_gz;
 } Ctx;
 
 static void ctx_init(Ctx *c, const OrcScene *s)
@@ -257,6 +265,12 @@ static void ctx_init(Ctx *c, const OrcScene *s)
     c->mie_n = s->mie_count;
     c->max_depth = s->max_depth;
     c->mode = s->mode;
+    c->estimator = s->estimator;
+    c->maj = s->majorant;
+    c->maj_bias = s->maj_bias;
+    c->maj_gx = s->maj_gx;
+    c->maj_gy = s->maj_gy;
+    c->maj_gz = s->maj_gz;
 }
 
 /* Exposes the derived uniforms so tests can compare them with the product's. */
@@ -321,6 +335,130 @@ static Event next_scattering_event(const Ctx *c, float optical_distance, v3 pos,
     }
     Event e = { scattered, scatter_pos, transmittance };
     return e;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DELTA estimator (not in the reference): Woodcock tracking of the SAME medium -- sigma(x) =
+ * densityMultiplier * trilinear(texture)/255, the field the reference's march samples once per
+ * step -- over a grid of 4x4x4-texel bricks with majorants.
+ *
+ *   brick b (per axis) covers base texels [4b - bias, 4b - bias + 3]; its majorant is the max of
+ *   the texels [lo-1, lo+5]^3 (clamped): every texel a trilinear footprint based in the brick
+ *   can read, plus one texel of slack on each side for positions that sit on a boundary.
+ *   sigma_bar = (float)M * (1/255.f) * densityMultiplier.
+ *
+ *   flight from pos along dir:  tp = pos*scale - 0.5 (texel coordinates), v = dir*scale;
+ *   3-D DDA over the bricks in the ray parameter t (box units): tmax_a = (bound_a - tp_a)/v_a,
+ *   tdelta_a = 4/|v_a|.  In a brick with M > 0:  dt = -log(1 - rnd)/sigma_bar; if t + dt reaches
+ *   the brick's exit the flight moves on to the next brick (the exponential is memoryless);
+ *   otherwise t += dt, p = fma(dir, t, pos), sigma = sample(p) [one density lookup], and the
+ *   collision is real when rnd * sigma_bar < sigma.  Leaving the brick grid ends the flight
+ *   without a collision.  Unbiased for the trilinear medium; the reference's march is an
+ *   O(step)-biased estimator of the same free-flight distribution.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_majorant_grid(const uint32_t dims[3], float sample_step, int32_t out_bias_g[4])
+{
+    const float m = (float)(dims[0] > dims[1] ? (dims[0] > dims[2] ? dims[0] : dims[2]) : (dims[1] > dims[2] ? dims[1] : dims[2]));
+    const int32_t apron = (int32_t)ceilf((0.01f + 8.0f * sample_step) * m + 0.5f) + 1;
+    const int32_t bias = ((apron + 3) / 4) * 4;
+    out_bias_g[0] = bias;
+    out_bias_g[1] = ((int32_t)dims[0] + 2 * bias + 3) / 4 + 1;
+    out_bias_g[2] = ((int32_t)dims[1] + 2 * bias + 3) / 4 + 1;
+    out_bias_g[3] = ((int32_t)dims[2] + 2 * bias + 3) / 4 + 1;
+}
+
+ORC_API void orc_build_majorants(const uint8_t *texels, const uint32_t dims[3], int32_t bias, int32_t gx, int32_t gy,
+                                 int32_t gz, uint8_t *out)
+{
+    const int32_t nx = (int32_t)dims[0], ny = (int32_t)dims[1], nz = (int32_t)dims[2];
+#pragma omp parallel for schedule(static)
+    for (int32_t bz = 0; bz < gz; bz++) {
+        for (int32_t by = 0; by < gy; by++) {
+            for (int32_t bx = 0; bx < gx; bx++) {
+                uint8_t m = 0;
+                for (int32_t z = 4 * bz - bias - 1; z <= 4 * bz - bias + 5; z++) {
+                    const int32_t zc = clampi(z, 0, nz - 1);
+                    for (int32_t y = 4 * by - bias - 1; y <= 4 * by - bias + 5; y++) {
+                        const int32_t yc = clampi(y, 0, ny - 1);
+                        for (int32_t x = 4 * bx - bias - 1; x <= 4 * bx - bias + 5; x++) {
+                            const uint8_t v = texels[((size_t)zc * ny + yc) * nx + clampi(x, 0, nx - 1)];
+                            m = v > m ? v : m;
+                        }
+                    }
+                }
+                out[((size_t)bz * gy + by) * gx + bx] = m;
+            }
+        }
+    }
+}
+
+static Event delta_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCounters *k)
+{
+    Event e = { 0, pos, 1.0f };
+    const float tp[3] = { fmaf(pos.x, c->density.sx, -0.5f), fmaf(pos.y, c->density.sy, -0.5f),
+                          fmaf(pos.z, c->density.sz, -0.5f) };
+    const float v[3] = { dir.x * c->density.sx, dir.y * c->density.sy, dir.z * c->density.sz };
+    int32_t b[3], step[3];
+    float tmax[3], tdelta[3];
+    for (int a = 0; a < 3; a++) {
+        const int32_t cell = (int32_t)floorf(tp[a]) + c->maj_bias;
+        b[a] = cell >> 2;
+        if (v[a] > 0.0f) {
+            step[a] = 1;
+            tmax[a] = ((float)(((b[a] + 1) << 2) - c->maj_bias) - tp[a]) / v[a];
+            tdelta[a] = 4.0f / v[a];
+        } else if (v[a] < 0.0f) {
+            step[a] = -1;
+            tmax[a] = ((float)((b[a] << 2) - c->maj_bias) - tp[a]) / v[a];
+            tdelta[a] = 4.0f / -v[a];
+        } else {
+            step[a] = 0;
+            tmax[a] = INFINITY;
+            tdelta[a] = INFINITY;
+        }
+    }
+    float t = 0.0f;
+    for (;;) {
+        if (b[0] < 0 || b[1] < 0 || b[2] < 0 || b[0] >= c->maj_gx || b[1] >= c->maj_gy || b[2] >= c->maj_gz) {
+            e.pos = v3_make(fmaf(dir.x, t, pos.x), fmaf(dir.y, t, pos.y), fmaf(dir.z, t, pos.z));
+            return e; /* left the grid: no collision */
+        }
+        const float t_exit = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
+        const uint8_t M = c->maj[((size_t)b[2] * c->maj_gy + b[1]) * c->maj_gx + b[0]];
+        if (M != 0) {
+            const float sigma_bar = ((float)M * (1.0f / 255.0f)) * c->density_multiplier;
+            for (;;) {
+                const float u = orc_rnd(seed);
+                const float dt = -ct_logf(1.0f - u) / sigma_bar;
+                if (t + dt >= t_exit) {
+                    break;
+                }
+                t = t + dt;
+                const v3 p = v3_make(fmaf(dir.x, t, pos.x), fmaf(dir.y, t, pos.y), fmaf(dir.z, t, pos.z));
+                const float sigma = sample_cloud(c, p, k) * c->density_multiplier;
+                const float z = orc_rnd(seed);
+                if (z * sigma_bar < sigma) {
+                    e.scattered = 1;
+                    e.pos = p;
+                    return e;
+                }
+            }
+        }
+        t = t_exit;
+        const int a = (tmax[0] <= tmax[1]) ? ((tmax[0] <= tmax[2]) ? 0 : 2) : ((tmax[1] <= tmax[2]) ? 1 : 2);
+        b[a] += step[a];
+        tmax[a] += tdelta[a];
+    }
+}
+
+/* One free flight with the scene's estimator; MARCH draws its random number first (cloud.cuh:120). */
+static Event free_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCounters *k)
+{
+    if (c->estimator == 1) {
+        return delta_flight(c, seed, pos, dir, k);
+    }
+    const float xi = orc_rnd(seed);
+    return next_scattering_event(c, xi, pos, dir, k);
 }
 
 /* getInScattering, cloud.cuh:146-158 (NEE through the pre-integrated shadow volume). */
@@ -414,7 +552,7 @@ static v3 radiance_of_ray(const Ctx *c, v3 origin, v3 ray_dir, uint32_t seed, Or
 
     if (c->mode == 2) {
         /* singleScatterSunRadiance, :120-148 */
-        const Event e = next_scattering_event(c, orc_rnd(&seed), pos, direction, k);
+        const Event e = free_flight(c, &seed, pos, direction, k);
         if (e.scattered && in_box(c, e.pos)) {
             radiance = v3_add(radiance, in_scattering(c, e.pos, direction, 0, k));
         }
@@ -430,7 +568,7 @@ static v3 radiance_of_ray(const Ctx *c, v3 origin, v3 ray_dir, uint32_t seed, Or
             k->depth_capped++;
             break;
         }
-        const Event e = next_scattering_event(c, orc_rnd(&seed), pos, direction, k);
+        const Event e = free_flight(c, &seed, pos, direction, k);
         if (!e.scattered || !in_box(c, e.pos)) {
             break;
         }

@@ -41,6 +41,12 @@ class OrcScene(C.Structure):
         ("chopped_mie_tex", C.c_void_p),
         ("chopped_cdf_tex", C.c_void_p),
         ("mie_count", C.c_uint32),
+        ("estimator", C.c_int32),
+        ("majorant", C.c_void_p),
+        ("maj_bias", C.c_int32),
+        ("maj_gx", C.c_int32),
+        ("maj_gy", C.c_int32),
+        ("maj_gz", C.c_int32),
     ]
 
 
@@ -115,6 +121,8 @@ def lib(fast: bool = False):
     L.orc_inscatter.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_int32]
     L.orc_point_radiance_launch.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.POINTER(OrcCounters), C.c_int32]
+    L.orc_majorant_grid.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+    L.orc_build_majorants.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.orc_generate_scatter_samples.argtypes = [C.POINTER(OrcScene), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.orc_point_task_merge.restype = C.c_int32
     L.orc_point_task_merge.argtypes = [C.c_void_p, C.c_void_p]
@@ -187,6 +195,7 @@ class Oracle:
     light_color: tuple = (1.0, 1.0, 1.0)
     light_intensity: float = 1e6
     eye: tuple = (2.5, -0.4, 0.0)
+    estimator: int = 0
     threads: int = 0
     fast: bool = False
     inscatter: np.ndarray | None = None
@@ -220,6 +229,16 @@ class Oracle:
         s.chopped_mie_tex = self._tex[1].ctypes.data
         s.chopped_cdf_tex = self._tex[2].ctypes.data
         s.mie_count = 4096
+        s.estimator = self.estimator
+        if self.estimator == 1:
+            dims = np.array([nx, ny, nz], np.uint32)
+            grid = np.zeros(4, np.int32)
+            self.L.orc_majorant_grid(_ptr(dims), self.sample_step, _ptr(grid))
+            bias, gx, gy, gz = (int(v) for v in grid)
+            self.majorant = np.empty((gz, gy, gx), np.uint8)
+            self.L.orc_build_majorants(_ptr(self.density), _ptr(dims), bias, gx, gy, gz, _ptr(self.majorant))
+            s.majorant = self.majorant.ctypes.data
+            s.maj_bias, s.maj_gx, s.maj_gy, s.maj_gz = bias, gx, gy, gz
         self.scene = s
         if self.inscatter is None:
             self.inscatter = np.empty_like(self.density)

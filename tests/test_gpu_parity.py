@@ -25,7 +25,7 @@ def rel_l2(a, b):
 def make_pair(tex, w, h, mode=0, **kw):
     tr = ds.CloudTracer(tex, width=w, height=h, mode=mode, **kw)
     okw = {k: v for k, v in kw.items() if k in ("cloud_size_m", "mean_free_path_m", "sample_step", "max_depth",
-                                                 "light_direction", "light_color", "light_intensity")}
+                                                 "light_direction", "light_color", "light_intensity", "estimator")}
     orc = O.Oracle(tex, w, h, mode=mode, fast=True, **okw)
     return tr, orc
 
@@ -286,6 +286,88 @@ def test_cpp_host_cli_matches_python_path(tmp_path):
         tr.close()
     bad = subprocess.run([str(cli), "procedural:32", "--mode", "bogus"], capture_output=True, text=True)
     assert bad.returncode == 1 and "Invalid Render Mode" in bad.stdout      # CloudMaterial.cpp:62 / main.cpp:65-76
+
+
+# ---- DELTA estimator (Woodcock tracking; oracle twin: delta_flight in oracle/ct_oracle.c) -------------
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_delta_estimator_bit_exact_vs_oracle(mode):
+    tex = sphere_volume(32, seed=31)
+    w, h = 32, 24
+    tr, orc = make_pair(tex, w, h, mode=mode, estimator=1)
+    mean, m2 = orc.render(6)
+    tr.render_accumulate(1, 2)
+    tr.render_accumulate(3, 4)
+    assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2)
+    assert tr.counters() == orc.counters.as_dict()
+    tr.close()
+
+
+@pytest.mark.parametrize("dims,radius", [((64, 64, 64), 0.16), ((96, 72, 80), 0.12)])
+def test_delta_brick_replay_is_bit_exact(dims, radius):
+    """Small cloud in a big box: the kernel crosses runs of empty bricks by replaying DDA steps
+    without loading their majorants; the oracle walks them one by one."""
+    tex = sphere_volume(dims=dims, radius=radius, seed=33)
+    w, h = 40, 32
+    tr, orc = make_pair(tex, w, h, mode=0, estimator=1)
+    mean, _ = orc.render(3)
+    tr.render_accumulate(1, 3)
+    assert np.array_equal(tr.mean(), mean)
+    assert tr.counters() == orc.counters.as_dict()
+    for eye in ((0.2, 2.4, 0.3), (-0.5, -0.3, -2.3), (0.05, 0.0, 0.1)):     # last one: camera inside the box
+        U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0.3), (0, 1, 0), 40.0, w / h)
+        tr.set_camera(eye, U, V, W)
+        orc.set_camera(eye, U, V, W)
+        tr.render_subframe(5)
+        assert np.array_equal(tr.frame(), orc.render_subframe(5))
+    tr.close()
+
+
+def test_delta_shards_and_point_tasks():
+    tex = sphere_volume(32, seed=35)
+    w, h = 40, 24
+    whole = ds.CloudTracer(tex, width=w, height=h, estimator=1)
+    whole.render_accumulate(1, 3)
+    merged = np.zeros((h, w, 4), np.float32)
+    for i in range(2):
+        sh = ds.CloudTracer(tex, width=w, height=h, estimator=1, shard_index=i, shard_count=2)
+        sh.render_accumulate(1, 3)
+        merged += sh.mean()
+        sh.close()
+    assert np.array_equal(merged, whole.mean())
+    whole.close()
+    rng = np.random.default_rng(3)
+    pos = (rng.random((100, 3), dtype=np.float32) - 0.5) * 0.5
+    d = rng.normal(size=(100, 3)).astype(np.float32)
+    tr = ds.CloudTracer(tex, width=8, height=8, mode=1, estimator=1)
+    orc = O.Oracle(tex, 8, 8, mode=1, estimator=1, fast=True)
+    got = tr.point_radiance_launch(ds.make_point_tasks(pos, d), 1, 5)
+    ref = orc.point_radiance_launch(ds.make_point_tasks(pos, d), 1, 5)
+    assert got.tobytes() == ref.tobytes()
+    tr.close()
+
+
+def test_delta_agrees_with_march_statistically():
+    """DELTA is an unbiased estimator of the medium that the reference's march samples with an
+    O(step) bias.  With the reference's 7000 m cloud the optical depth per step reaches 1.37 and the
+    march reads 5-10 % low (tools/march_delta_convergence.py); at a tenth of
+    that density the bias is below the noise and the two images must agree."""
+    tex = ds.make_procedural_cloud(96)
+    w = h = 48
+    spp = 2048
+    imgs = []
+    for est in (0, 1):
+        tr = ds.CloudTracer(tex, width=w, height=h, estimator=est, cloud_size_m=700.0)
+        tr.render_accumulate(1, spp)
+        imgs.append((tr.mean()[..., 0].astype(np.float64), tr.m2()[..., 0].astype(np.float64)))
+        tr.close()
+    (m0, v0), (m1, v1) = imgs
+    se_mean = np.sqrt((v0 + v1).sum()) / (spp * m0.size)
+    assert abs(m1.mean() - m0.mean()) < 4 * se_mean + 0.01 * m0.mean(), (m0.mean(), m1.mean(), se_mean)
+    # 8x8-pixel block means against the combined 4-sigma confidence interval of the two estimates
+    b0 = m0.reshape(6, 8, 6, 8).mean(axis=(1, 3))
+    b1 = m1.reshape(6, 8, 6, 8).mean(axis=(1, 3))
+    se = np.sqrt((v0 + v1).reshape(6, 8, 6, 8).sum(axis=(1, 3))) / (64 * spp)
+    assert np.all(np.abs(b1 - b0) <= 4 * se + 0.02 * np.maximum(b0, 1e-3)), (np.abs(b1 - b0) / (se + 1e-12)).max()
 
 
 def test_golden_fixture_on_gpu():

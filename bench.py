@@ -7,11 +7,11 @@ reduce of the accumulated radiance buffer).
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one progressive batch of --spp-per-step (default 64) subframes of the whole frame:
-estimator kernel + Welford accumulate kernel, plus (N>1) the reduce of the W*H float4 radiance
-buffer to rank 0.  (The reference updates its display every 10 subframes and saves every 40,
-Camera.cpp:189,211; a launch cannot be shorter than its longest 2000-bounce path, ~12 ms, so
-batches of 64 keep that tail below 15 % of a step.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
+A "step" = one progressive batch of --spp-per-step (default 128 x n_gpus) subframes of the whole
+frame: estimator kernel + Welford accumulate kernel, plus (N>1) the reduce of the W*H float4
+radiance buffer to rank 0.  (The reference updates its display every 10 subframes and saves every
+40, Camera.cpp:189,211; a launch cannot be shorter than its deepest 2000-bounce path, ~11 ms, so
+batches of 128 subframes per GPU keep that tail near 10 % of a step: 8 updates per 1024-spp image.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
 before the timed region and resident in HBM).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp-per-step", type=int, default=0,
                     help="subframes per progressive batch (one estimator launch + one accumulate launch); "
-                         "default 64 x n_gpus, i.e. a constant number of samples per GPU per launch")
+                         "default 128 x n_gpus, i.e. a constant number of samples per GPU per launch")
     ap.add_argument("--mode", type=int, default=0, help="0 totalRadiance (Mie multi-scatter + NEE)")
     ap.add_argument("--estimator", type=int, default=0, choices=(0, 1),
                     help="0 MARCH = the reference's free-flight sampler (the parity path, default); "
@@ -115,7 +115,7 @@ def main():
             dist.init_process_group(args.backend)
 
     W, H = args.width, args.height
-    S = args.spp_per_step if args.spp_per_step > 0 else 64 * world
+    S = args.spp_per_step if args.spp_per_step > 0 else 128 * world
     t_setup = time.perf_counter()
     tex = ds.make_procedural_cloud(args.volume)
     flags = _lib.CT_FLAG_SIMPLE_KERNEL if args.simple_kernel else 0

@@ -374,6 +374,38 @@ CT_DEV f3 in_scattering(const DevScene &sc, f3 pos, f3 dir, bool chopped)
     return scale3(l, sc.sun_ratio);
 }
 
+// The same NEE in two halves, so that its three loads (two phase-table entries, the shadow
+// volume's footprint) are in flight while the direction sampling runs: identical arithmetic.
+struct NeeLoads {
+    float a, b, w;     // phase table entries and filter weight
+    uint2 cell;        // shadow-volume footprint
+};
+
+CT_DEV NeeLoads in_scattering_issue(const DevScene &sc, f3 pos, f3 dir, bool chopped)
+{
+    NeeLoads n;
+    const float cos_light = dot3(mk3(sc.nlx, sc.nly, sc.nlz), dir);
+    const float u = (cos_light + 1) / 2;
+    const float *table = chopped ? sc.chopped : sc.mie;
+    const float x = fmaf(u, (float)kMieN, -0.5f);
+    const int32_t i = (int32_t)floorf(x);
+    n.a = table[min(max(i, 0), kMieN - 1)];
+    n.b = table[min(max(i + 1, 0), kMieN - 1)];
+    n.w = fract_(x);
+    uint32_t meta_unused;
+    n.cell = fetch_cell(sc, sc.ibricks, pos, meta_unused);
+    return n;
+}
+
+CT_DEV f3 in_scattering_finish(const DevScene &sc, const NeeLoads &n, f3 pos)
+{
+    const float phase = fmaf(n.w, n.b - n.a, n.a);
+    const float ins = filter_at(sc, n.cell, pos);
+    f3 l = scale3(mk3(sc.lr, sc.lg, sc.lb), ins);
+    l = scale3(l, phase);
+    return scale3(l, sc.sun_ratio);
+}
+
 enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_BOUNCE = 2 };
 
 // 1 / max per-axis advance of one march step, in texels (approximate reciprocal is fine: it only
@@ -513,7 +545,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             }
             if (state == ST_BOUNCE) {
                 const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
-                rad = add3(rad, in_scattering(sc, pos, dir, chopped));
+                const NeeLoads nee = in_scattering_issue(sc, pos, dir, chopped);
                 c_il += 1;
                 bool go = (MODE != 2);
                 if (go) {
@@ -524,6 +556,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                         go = false;
                     }
                 }
+                rad = add3(rad, in_scattering_finish(sc, nee, pos));
                 if (go) {
                     xi = u24_to_float(lcg24(seed));
                     T = 1;
@@ -821,15 +854,15 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
         }
 
         bool finished = false;
-        if (nb != 0) {
-            // ---------------- scatter (eager) ----------------
+        if (nb != 0 && (nb >= sc.scatter_min || nm == 0)) {
+            // ---------------- scatter ----------------
             if (STATS) {
                 st_scat += 1;
                 st_scat_l += nb;
             }
             if (state == ST_BOUNCE) {
                 const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
-                rad = add3(rad, in_scattering(sc, pos, dir, chopped));
+                const NeeLoads nee = in_scattering_issue(sc, pos, dir, chopped);
                 c_il += 1;
                 bool go = (MODE != 2);
                 if (go) {
@@ -840,6 +873,7 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
                         go = false;
                     }
                 }
+                rad = add3(rad, in_scattering_finish(sc, nee, pos));
                 if (go) {
                     dda_begin(sc, dda, pos, dir);
                     state = ST_MARCH;

@@ -294,7 +294,8 @@ class CloudTracer:
         out = np.zeros(16, np.uint64)
         check(self.L.ct_debug_stats(self.h, _p(out)), self.h)
         names = ["regen_phases", "regen_lanes", "march_phases", "march_lanes", "scatter_phases", "scatter_lanes",
-                 "fetched_steps", "fetched_zero_cells", "skipped_steps"]
+                 "fetched_steps", "fetched_zero_cells", "skipped_steps", "zero_cells_nonfree_brick",
+                 "zero_cells_free_brick_d1"]
         return {n: int(v) for n, v in zip(names, out)}
 
     def debug_cdf_inversion(self, first_u24: int, count: int) -> np.ndarray:

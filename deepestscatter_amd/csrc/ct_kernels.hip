@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
     uint32_t c_dl = 0, c_il = 0, c_cap = 0; // per-lane tallies
     // scheduler diagnostics (STATS builds only), see ct_debug_stats
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
-    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0;
+    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0;
 
     for (;;) {
         // ---------------- regenerate ----------------
@@ -529,12 +529,10 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         const uint64_t bouncing = __builtin_amdgcn_ballot_w64(state == ST_BOUNCE);
         const uint32_t nm = (uint32_t)__builtin_popcountll(marching);
         const uint32_t nb = (uint32_t)__builtin_popcountll(bouncing);
-        if ((marching | bouncing) == 0) {
-            if (drained && q_next == q_end) {
-                break;
-            }
-            continue; // everything idle: go regenerate
+        if ((marching | bouncing) == 0 && drained && q_next == q_end) {
+            break;
         }
+        // (everything idle but samples left: both phases below are no-ops and the loop regenerates)
 
         bool finished = false;
         if (nb * sc.scatter_den > nm * sc.scatter_num && (nb >= sc.scatter_min || nm == 0)) {
@@ -574,6 +572,12 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 st_march += 1;
                 st_march_l += nm;
             }
+            // A burst of up to sc.march_burst steps per scheduler visit: the scheduler's own
+            // instructions are paid once per burst, and the lanes that collide meanwhile wait for a
+            // fuller scatter phase.  The burst ends early when enough lanes wait for the scatter
+            // phase or for new samples, or nobody marches any more.
+            uint32_t burst = sc.march_burst;
+            for (;;) {
             if (state == ST_MARCH) {
                 // Free-space skip: every brick within Chebyshev distance dfree-1 of the one `pos` is
                 // in is free, so the next n steps can neither collide (all 8 texels are 0, T *= 1)
@@ -598,6 +602,8 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 if (STATS) {
                     st_fetch += 1;
                     st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
+                    st_zero_d0 += ((cell.x | cell.y) == 0u && dfree == 0u) ? 1u : 0u;
+                    st_zero_d1 += ((cell.x | cell.y) == 0u && dfree == 1u) ? 1u : 0u;
                 }
                 bool collided = false;
                 if ((cell.x | cell.y) != 0u) {
@@ -616,12 +622,28 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 // both are known to hold (see DevScene), so the six comparisons are skipped.
                 const bool inside = (meta & 0x80u) != 0u || in_box(sc, pos);
                 if (!inside) {
-                    finished = true;
+                    ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                    if (ba.cost) {
+                        atomicAdd(&ba.cost[group], depth);
+                    }
                     state = ST_IDLE;
                 } else if (collided) {
                     state = ST_BOUNCE;
                     dfree = 0;
                 }
+            }
+            if (--burst == 0u) {
+                break;
+            }
+            const uint32_t m_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_MARCH));
+            const uint32_t b_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_BOUNCE));
+            if (m_now == 0u || b_now >= sc.burst_scatter || 64u - m_now - b_now >= sc.burst_idle) {
+                break;
+            }
+            if (STATS) {
+                st_march += 1;
+                st_march_l += m_now;
+            }
             }
         }
         if (finished) {
@@ -645,9 +667,9 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         vals[i] = v;
     }
     if (STATS) {
-        uint32_t sv[3] = { st_fetch, st_zero, st_skip };
+        uint32_t sv[5] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1 };
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 5; i++) {
             uint32_t v = sv[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -665,6 +687,8 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             atomicAdd(&ba.stats[6], (unsigned long long)sv[0]);
             atomicAdd(&ba.stats[7], (unsigned long long)sv[1]);
             atomicAdd(&ba.stats[8], (unsigned long long)sv[2]);
+            atomicAdd(&ba.stats[9], (unsigned long long)sv[3]);
+            atomicAdd(&ba.stats[10], (unsigned long long)sv[4]);
         }
     }
     if (lane == 0) {

@@ -24,7 +24,7 @@ HEADERS = [CSRC / "ct_device.hpp", CSRC / "ct_internal.hpp", ROOT / "include" / 
 
 # -ffp-contract=off is part of the numeric contract (include/ct_fmath.h): results must be
 # bit-identical to the CPU oracle, so no implicit FMA contraction and no fast-math.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-value"]
 
 

@@ -295,7 +295,8 @@ class CloudTracer:
         check(self.L.ct_debug_stats(self.h, _p(out)), self.h)
         names = ["regen_phases", "regen_lanes", "march_phases", "march_lanes", "scatter_phases", "scatter_lanes",
                  "fetched_steps", "fetched_zero_cells", "skipped_steps", "zero_cells_nonfree_brick",
-                 "zero_cells_free_brick_d1"]
+                 "zero_cells_free_brick_d1", "skip_loop_wave_iterations", "waves_xcd_eq_block_mod8", "waves",
+                 "stolen_jobs"]
         return {n: int(v) for n, v in zip(names, out)}
 
     def debug_cdf_inversion(self, first_u24: int, count: int) -> np.ndarray:

@@ -46,10 +46,14 @@ struct CtHandle_ {
     uint32_t *d_job_group = nullptr, *d_job_sub = nullptr; // job list of the current batch size
     uint32_t n_groups = 0, groups_capacity = 0;
     uint32_t n_jobs = 0, jobs_capacity = 0, jobs_S = 0;
+    uint32_t q_begin[kQueues + 2] = {}; // job ranges of the per-XCD queues + the shared one
     uint64_t own_pixels = 0, hit_pixels = 0;
     bool queue_dirty = true, order_tuned = false;
+    bool queues_enabled = true;          // per-XCD regions (CT_XCD_QUEUES=0: one global list)
+    float shared_depth = 64.f;           // groups at least this deep (bounces) use the shared queue
     std::vector<uint32_t> group_order;   // groups, most expensive first (identity until tuned)
-    std::vector<float> group_depth;      // measured mean path depth per group (0 until tuned)
+    std::vector<float> group_depth;      // measured mean path cost per group (0 until tuned), in the
+                                         // units of BatchArgs::cost
     unsigned long long host_paths = 0, host_hits = 0; // paths / box hits of the persistent path
     uint32_t *d_queue = nullptr;
     unsigned long long *d_counters = nullptr; // kCounterCount + 1 (unconverged) + kStatCount
@@ -277,8 +281,15 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.scatter_min = 1;
     // measured (profiles/README.md, burst sweep): 1207 Msamples/s without bursts, 1453 with 8/32/32
     d.march_burst = 8;
-    d.burst_scatter = 32;
+    d.burst_scatter = 48;
     d.burst_idle = 32;
+    h->queues_enabled = true;
+    if (const char *e = getenv("CT_XCD_QUEUES")) {
+        h->queues_enabled = atoi(e) != 0;
+    }
+    if (const char *e = getenv("CT_SHARED_DEPTH")) {
+        h->shared_depth = (float)atof(e);
+    }
     if (const char *e = getenv("CT_MARCH_BURST")) {
         d.march_burst = (uint32_t)std::min(1024, std::max(1, atoi(e)));
     }
@@ -377,7 +388,7 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, dmalloc(&h->d_screen, pixels));
     HIPCHK(h, dmalloc(&h->d_colsum, s->width));
     HIPCHK(h, dmalloc(&h->d_avg, 1));
-    HIPCHK(h, dmalloc(&h->d_queue, 1));
+    HIPCHK(h, dmalloc(&h->d_queue, kQueues + 1));
     HIPCHK(h, dmalloc(&h->d_counters, kCounterCount + 1 + kStatCount));
     HIPCHK(h, hipMemsetAsync(h->d_frame, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_mean, 0, pixels * sizeof(float4), h->stream));
@@ -575,20 +586,66 @@ static int build_jobs(CtHandle h, uint32_t S)
     if (h->jobs_S == S) {
         return CT_OK;
     }
+    // One queue per XCD: groups are in tile-Morton order, so a contiguous range of them is a
+    // compact image region whose paths read a compact part of the volume.  The ranges are cut at
+    // equal shares of the measured cost (path depth + the primary march), not of the pixel count.
+    // cost units per bounce (BatchArgs::cost): MARCH counts fetches + 4 per bounce, DELTA bounces
+    const float unit = (h->scene.estimator == CT_EST_DELTA) ? 1.f : 16.f;
+    const uint32_t nq = (h->queues_enabled && h->n_groups >= (uint32_t)kQueues) ? (uint32_t)kQueues : 1u;
+    // Groups whose paths are deep (mean cost >= shared_depth bounces) go to the shared queue.
+    const float shared_cost = h->shared_depth * unit;
+    std::vector<uint8_t> queue_of(h->n_groups, 0);
+    {
+        double total = 0;
+        for (uint32_t g = 0; g < h->n_groups; g++) {
+            if (nq > 1u && h->group_depth[g] >= shared_cost) {
+                queue_of[g] = (uint8_t)kQueues;
+            } else {
+                total += (double)h->group_depth[g] + unit;
+            }
+        }
+        double run = 0;
+        for (uint32_t g = 0; g < h->n_groups; g++) {
+            if (queue_of[g] == (uint8_t)kQueues) {
+                continue;
+            }
+            const double w = (double)h->group_depth[g] + unit;
+            queue_of[g] = (uint8_t)std::min<double>(nq - 1, std::floor((run + 0.5 * w) / total * nq));
+            run += w;
+        }
+    }
     std::vector<uint32_t> jg, js;
     jg.reserve((size_t)h->n_groups * ((S + 7) / 8));
     js.reserve(jg.capacity());
-    for (uint32_t g : h->group_order) {
-        const float d = h->group_depth[g];
-        uint32_t len = 8;
-        if (d > 0.f) {
-            len = (uint32_t)std::min(8.f, std::max(1.f, 256.f / d));
-        }
-        for (uint32_t s0 = 0; s0 < S; s0 += len) {
-            jg.push_back(g);
-            js.push_back(s0 | (std::min(len, S - s0) << 16));
+    std::vector<double> q_weight(kQueues + 1, 0.0);
+    for (uint32_t x = 0; x <= (uint32_t)kQueues; x++) {
+        h->q_begin[x] = (uint32_t)jg.size();
+        for (uint32_t g : h->group_order) {
+            if (queue_of[g] != x) {
+                continue;
+            }
+            const float d = h->group_depth[g];
+            q_weight[x] += (double)d + unit;
+            uint32_t len = 8;
+            if (d > 0.f) {
+                len = (uint32_t)std::min(8.f, std::max(1.f, 256.f * unit / d));
+            }
+            for (uint32_t s0 = 0; s0 < S; s0 += len) {
+                jg.push_back(g);
+                js.push_back(s0 | (std::min(len, S - s0) << 16));
+            }
         }
     }
+    h->q_begin[kQueues + 1] = (uint32_t)jg.size();
+    if (getenv("CT_STATS")) {
+        fprintf(stderr, "[cloudtrace] job queues (S=%u):", S);
+        for (int x = 0; x <= kQueues; x++) {
+            fprintf(stderr, " q%d jobs %u weight %.0f;", x, h->q_begin[x + 1] - h->q_begin[x], q_weight[x]);
+        }
+        fprintf(stderr, "\n");
+    }
+    // (nq == 1: everything sits in queue 0 and the other XCDs' waves steal from it -- one global
+    // cost-sorted list, the behaviour before the queues were split)
     h->n_jobs = (uint32_t)jg.size();
     if (h->n_jobs > h->jobs_capacity) {
         for (void *p : { (void *)h->d_job_group, (void *)h->d_job_sub }) {
@@ -696,12 +753,15 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
     ba.job_sub = h->d_job_sub;
     ba.cost = h->order_tuned ? nullptr : h->d_cost;
     ba.n_jobs = h->n_jobs;
+    for (int x = 0; x <= kQueues + 1; x++) {
+        ba.q_begin[x] = h->q_begin[x];
+    }
     ba.first_subframe = first;
     ba.S = S;
     ba.queue = h->d_queue;
     ba.counters = h->d_counters;
     ba.stats = h->d_counters + kCounterCount + 1;
-    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, (kQueues + 1) * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if (simple) {
         for (uint32_t s = 0; s < S; s++) {
@@ -876,7 +936,7 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         HIPCHK(h, hipMemcpyAsync(d_jg, jg.data(), jg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(d_js, js.data(), js.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemsetAsync(d_cost, 0, n_groups * sizeof(uint32_t), h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_queue, 0, (kQueues + 1) * sizeof(uint32_t), h->stream));
         HIPCHK(h, launch_point_rays(h->dev, d_tasks, count, n_pad, d_primary, d_pixels, h->stream));
         BatchArgs ba{};
         ba.frames = d_frames;
@@ -887,6 +947,7 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         ba.job_sub = d_js;
         ba.cost = nullptr;
         ba.n_jobs = (uint32_t)jg.size();
+        split_queues_evenly(ba);
         ba.first_subframe = first_frame_id;
         ba.S = launches;
         ba.queue = h->d_queue;

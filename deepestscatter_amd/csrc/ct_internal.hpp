@@ -11,6 +11,7 @@ namespace ct {
 constexpr int kTile = 8;            // pixel tile edge: 8x8 = one wave of primary rays
 constexpr int kCounterCount = 6;    // paths, box_hits, density, inscatter, scatter, capped
 constexpr int kStatCount = 16;      // scheduler diagnostics (ct_debug_stats)
+constexpr int kQueues = 8;          // one job queue per XCD (MI355X: 8 XCDs, each with its own L2)
 
 // One progressive batch: subframes first .. first+S-1 of the handle's own tiles.
 struct BatchArgs {
@@ -27,12 +28,19 @@ struct BatchArgs {
     // every wave still stays on one 64-pixel group at a time (cache locality).
     const uint32_t *job_group;
     const uint32_t *job_sub;
-    uint32_t *cost;            // per group: sum of path depths, feeds the next job list; NULL once
+    uint32_t *cost;            // per group: sum of path costs (MARCH: fetches + 4 per bounce; DELTA:
+                               // bounces), feeds the next job list; NULL once
                                // the order is tuned (hundreds of waves share a group at large S)
     uint32_t n_jobs;
+    // Queue x < kQueues holds jobs [q_begin[x], q_begin[x+1]): the pixel groups of one compact image
+    // region, so that the waves of one XCD share that region's bricks in their L2.  Queue kQueues
+    // is shared: the jobs of the deepest groups, which every wave of the chip must start on at
+    // once (a launch cannot be shorter than its deepest path).  A wave drains the shared queue,
+    // then the queue of the XCD it runs on, then the following ones (work stealing).
+    uint32_t q_begin[kQueues + 2];
     uint32_t first_subframe;   // 1-based subframeId of slice 0
     uint32_t S;
-    uint32_t *queue;           // global work counter, zero before launch
+    uint32_t *queue;           // kQueues + 1 work counters, zero before launch
     unsigned long long *counters; // kCounterCount
     unsigned long long *stats;    // kStatCount
 };
@@ -41,6 +49,15 @@ struct LaunchShape {
     int blocks;
     int threads;
 };
+
+// Evenly split job list (no locality information): point tasks, first launches.
+inline void split_queues_evenly(BatchArgs &ba)
+{
+    for (int x = 0; x <= kQueues; x++) {
+        ba.q_begin[x] = (uint32_t)(((uint64_t)ba.n_jobs * (uint32_t)x) / kQueues);
+    }
+    ba.q_begin[kQueues + 1] = ba.n_jobs; // empty shared queue
+}
 
 // Tile -> shard map (also exported as ct_tile_owner).
 __host__ __device__ inline uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_t shard_count)

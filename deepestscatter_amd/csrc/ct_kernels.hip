@@ -417,6 +417,39 @@ CT_DEV float inv_max_advance(const DevScene &sc, f3 stepv)
 }
 
 
+// The XCD this wave runs on (XCC_ID, hardware register 20, bits 3:0).
+CT_DEV uint32_t xcd_id()
+{
+    return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (uint32_t)(kQueues - 1);
+}
+
+// Next job for this wave: from the queue it is working on (first the shared one), else from its
+// XCD's, else from the following ones.  Wave-uniform.  Returns false when every queue is empty.
+CT_DEV bool take_job(const BatchArgs &ba, uint32_t lane, uint32_t &q_cur, uint32_t &q_tried, uint32_t &job)
+{
+    while (q_tried < (uint32_t)kQueues) {
+        const uint32_t begin = ba.q_begin[q_cur], end = ba.q_begin[q_cur + 1];
+        if (begin != end) {
+            uint32_t j = 0;
+            if (lane == 0) {
+                j = atomicAdd(&ba.queue[q_cur], 1u);
+            }
+            j = __builtin_amdgcn_readfirstlane(j);
+            if (j < end - begin) {
+                job = begin + j;
+                return true;
+            }
+        }
+        if (q_cur == (uint32_t)kQueues) {
+            q_cur = xcd_id();
+        } else {
+            q_tried += 1;
+            q_cur = (q_cur + 1u) & (uint32_t)(kQueues - 1);
+        }
+    }
+    return false;
+}
+
 CT_DEV uint32_t lane_rank(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -439,6 +472,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
     const uint32_t lane = threadIdx.x & 63u;
     f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), stepv = mk3(0, 0, 0), rad = mk3(0, 0, 0);
     uint32_t seed = 0, depth = 0, out_idx = 0, group = 0;
+    uint32_t work = 0;      // scheduler visits this path has cost so far (feeds the job order)
     float xi = 0, T = 1;
     uint32_t dfree = 0;     // free-space distance of the brick `pos` is in (0 = unknown / none)
     float inv_maxd = 0;     // 1 / (largest per-axis texel advance of one step)
@@ -446,11 +480,12 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
 
     // wave-uniform bookkeeping (lives in SGPRs): the current job and the samples left in it
     uint32_t q_next = 0, q_end = 0, job_g = 0, job_s0 = 0;
+    uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
     uint32_t c_dl = 0, c_il = 0, c_cap = 0; // per-lane tallies
     // scheduler diagnostics (STATS builds only), see ct_debug_stats
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
-    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0;
+    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0;
 
     for (;;) {
         // ---------------- regenerate ----------------
@@ -459,13 +494,12 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         if ((n_idle >= sc.regen_min || n_idle == 64u) && !(drained && q_next == q_end)) {
             if (q_next == q_end) {
                 uint32_t j = 0;
-                if (lane == 0) {
-                    j = atomicAdd(ba.queue, 1u);
-                }
-                j = __builtin_amdgcn_readfirstlane(j);
-                if (j >= ba.n_jobs) {
+                if (!take_job(ba, lane, q_cur, q_tried, j)) {
                     drained = true;
                 } else {
+                    if (STATS) {
+                        st_stolen += (q_tried != 0u) ? 1u : 0u;
+                    }
                     const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
                     job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
                     job_s0 = sub & 0xffffu;
@@ -498,6 +532,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                         seed = tea4(__float_as_uint(p1.w), ba.first_subframe + s); // :21
                         rad = mk3(0, 0, 0);
                         depth = 0;
+                        work = 0;
                         if (MODE == 1) {
                             dir = new_direction(lds.cdf, lds.guide, seed, dir);  // :86
                         }
@@ -542,26 +577,41 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 st_scat_l += nb;
             }
             if (state == ST_BOUNCE) {
-                const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
-                const NeeLoads nee = in_scattering_issue(sc, pos, dir, chopped);
-                c_il += 1;
-                bool go = (MODE != 2);
-                if (go) {
-                    dir = new_direction(lds.cdf, lds.guide, seed, dir);
-                    depth++;
-                    if (depth == sc.max_depth) {
-                        c_cap += 1;
-                        go = false;
-                    }
+                // The collision's back-off (cloud.cuh:99) was left for this phase: in the march phase
+                // one lane in fifteen collides per step, so its log and two divisions would run for
+                // nearly every wave at 7 % lane occupancy.  `inv_maxd` carries the density sampled at
+                // the collision, `dfree` the brick's "interior" flag (both are reset below).
+                {
+                    const float lg = logf_above_one(xi / T);
+                    const float inv = 1.0f / inv_maxd;
+                    pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
                 }
-                rad = add3(rad, in_scattering_finish(sc, nee, pos));
-                if (go) {
-                    xi = u24_to_float(lcg24(seed));
-                    T = 1;
-                    stepv = scale3(dir, sc.sample_step);
-                    inv_maxd = inv_max_advance(sc, stepv);
-                    dfree = 0;
-                    state = ST_MARCH;
+                // isInBox(scatterPos), cloudRadianceMaterials.cu:49-52
+                if (dfree != 0u || in_box(sc, pos)) {
+                    const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
+                    const NeeLoads nee = in_scattering_issue(sc, pos, dir, chopped);
+                    c_il += 1;
+                    work += 4u;
+                    bool go = (MODE != 2);
+                    if (go) {
+                        dir = new_direction(lds.cdf, lds.guide, seed, dir);
+                        depth++;
+                        if (depth == sc.max_depth) {
+                            c_cap += 1;
+                            go = false;
+                        }
+                    }
+                    rad = add3(rad, in_scattering_finish(sc, nee, pos));
+                    if (go) {
+                        xi = u24_to_float(lcg24(seed));
+                        T = 1;
+                        stepv = scale3(dir, sc.sample_step);
+                        inv_maxd = inv_max_advance(sc, stepv);
+                        dfree = 0;
+                        state = ST_MARCH;
+                    } else {
+                        finished = true;
+                    }
                 } else {
                     finished = true;
                 }
@@ -592,6 +642,13 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                     c_dl += (uint32_t)n;
                     if (STATS) {
                         st_skip += (uint32_t)n;
+                        // wave-level iterations of the replay loop = the largest n of the wave
+                        int wmax = n;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) {
+                            wmax = max(wmax, __shfl_xor(wmax, off));
+                        }
+                        st_skip_iters += (lane_rank(__builtin_amdgcn_ballot_w64(true)) == 0u) ? (uint32_t)wmax : 0u;
                     }
                 }
                 pos = add3(pos, stepv);
@@ -599,6 +656,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 const uint2 cell = fetch_cell(sc, sc.dbricks, pos, meta);
                 dfree = meta & 0x7fu;
                 c_dl += 1;
+                work += 1u;
                 if (STATS) {
                     st_fetch += 1;
                     st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
@@ -612,24 +670,22 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                     const float extinction = density * sc.sample_step;
                     T *= expf_inrange(-extinction);
                     if (xi > T) {
+                        // collision: scatterPos and its box test are evaluated by the scatter phase
                         collided = true;
-                        const float lg = logf_above_one(xi / T);
-                        const float inv = 1.0f / density;
-                        pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
+                        inv_maxd = density;
                     }
                 }
-                // isInBox(pos) (no collision) / isInBox(scatterPos) (:49-52).  In an "interior" brick
-                // both are known to hold (see DevScene), so the six comparisons are skipped.
-                const bool inside = (meta & 0x80u) != 0u || in_box(sc, pos);
-                if (!inside) {
+                // isInBox(pos), the loop condition of cloud.cuh:87.  In an "interior" brick it is
+                // known to hold (see DevScene), so the six comparisons are skipped.
+                if (collided) {
+                    state = ST_BOUNCE;
+                    dfree = meta & 0x80u;
+                } else if ((meta & 0x80u) == 0u && !in_box(sc, pos)) {
                     ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
                     if (ba.cost) {
-                        atomicAdd(&ba.cost[group], depth);
+                        atomicAdd(&ba.cost[group], work);
                     }
                     state = ST_IDLE;
-                } else if (collided) {
-                    state = ST_BOUNCE;
-                    dfree = 0;
                 }
             }
             if (--burst == 0u) {
@@ -649,7 +705,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         if (finished) {
             ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
             if (ba.cost) {
-                atomicAdd(&ba.cost[group], depth);
+                atomicAdd(&ba.cost[group], work);
             }
             state = ST_IDLE;
         }
@@ -667,9 +723,9 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         vals[i] = v;
     }
     if (STATS) {
-        uint32_t sv[5] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1 };
+        uint32_t sv[6] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1, st_skip_iters };
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
+        for (int i = 0; i < 6; i++) {
             uint32_t v = sv[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -689,6 +745,10 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             atomicAdd(&ba.stats[8], (unsigned long long)sv[2]);
             atomicAdd(&ba.stats[9], (unsigned long long)sv[3]);
             atomicAdd(&ba.stats[10], (unsigned long long)sv[4]);
+            atomicAdd(&ba.stats[11], (unsigned long long)sv[5]);
+            atomicAdd(&ba.stats[12], (unsigned long long)(xcd_id() == (blockIdx.x & (uint32_t)(kQueues - 1)) ? 1u : 0u));
+            atomicAdd(&ba.stats[13], 1ull);
+            atomicAdd(&ba.stats[14], (unsigned long long)st_stolen);
         }
     }
     if (lane == 0) {
@@ -793,6 +853,7 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
     int state = ST_IDLE;
 
     uint32_t q_next = 0, q_end = 0, job_g = 0, job_s0 = 0;
+    uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
     uint32_t c_dl = 0, c_il = 0, c_cap = 0;
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
@@ -805,11 +866,7 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
         if ((n_idle >= sc.regen_min || n_idle == 64u) && !(drained && q_next == q_end)) {
             if (q_next == q_end) {
                 uint32_t j = 0;
-                if (lane == 0) {
-                    j = atomicAdd(ba.queue, 1u);
-                }
-                j = __builtin_amdgcn_readfirstlane(j);
-                if (j >= ba.n_jobs) {
+                if (!take_job(ba, lane, q_cur, q_tried, j)) {
                     drained = true;
                 } else {
                     const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);

@@ -67,6 +67,19 @@ struct DevScene {
     // distance, in bricks, capped, to the nearest brick that is not "free" = M == 0 and interior),
     // bit 7 = "interior" (every position whose base texel lies in the brick passes isInBox, and so
     // does a scatter position backed off from it).  They ride in the footprint's cache line.
+    // The MARCH estimator reads the density through a second brick array, `mbricks`: bricks of
+    // 3x4x4 texels whose 25 rows are [t0 t1 t2 t3 M] (4 texels = 3 + apron, then a meta byte), at
+    // byte lz*25 + ly*5 + lx like the others.  The first 8-byte load of a footprint based at
+    // (lx,ly,lz) starts at t_lx of row (ly,lz) and therefore always contains that row's M (at byte
+    // 4-lx): the march step needs two loads per lane, not three, and the L1 gather rate is what
+    // bounds this kernel.  M: bits 0-6 = c, the clearance in TEXELS of the row's three base texels
+    // (every footprint based within Chebyshev distance c of any of them is all zero and every such
+    // position passes isInBox; texel-granular, so rows inside partly filled bricks get one too),
+    // bit 7 = "interior" for the row's bases (1 <= base <= N-3 on every axis: isInBox holds for
+    // every position based there and for a scatter position backed off from it).
+    const uint8_t *mbricks;
+    int32_t m_bias_x;        // x bias of the 3-texel brick columns (multiple of 3)
+    int32_t m_gx, m_gxy;     // bricks per row / per slice of mbricks (y and z use brick_gy/gz, brick_bias)
     int32_t nx, ny, nz;    // texels
     float sx, sy, sz;      // box coordinate -> texel coordinate (textureScale * N)
     float bx, by, bz;      // bboxSize          (VDBCloud.cpp:104)
@@ -174,6 +187,25 @@ CT_DEV uint2 load_footprint_meta(const DevScene &sc, const uint8_t *bricks, int3
     return r;
 }
 
+// Footprint + row meta byte from the 3x4x4 march bricks (see DevScene::mbricks): two loads.
+CT_DEV uint2 load_footprint_m(const DevScene &sc, int32_t ix, int32_t iy, int32_t iz, uint32_t &meta)
+{
+    const uint32_t x = (uint32_t)(ix + sc.m_bias_x), y = (uint32_t)(iy + sc.brick_bias), z = (uint32_t)(iz + sc.brick_bias);
+    const uint32_t bx = __umul24(x, 43691u) >> 17; // x / 3, exact for x < 2^17
+    const uint32_t lx = x - __umul24(bx, 3u);
+    const uint32_t brick = __umul24(z >> 2, (uint32_t)sc.m_gxy) + __umul24(y >> 2, (uint32_t)sc.m_gx) + bx;
+    const uint32_t local = __umul24(z & 3u, 25u) + __umul24(y & 3u, 5u) + lx;
+    const uint8_t *p = sc.mbricks + (((size_t)brick << 7) | local);
+    uint2 a, c;
+    __builtin_memcpy(&a, p, 8);       // t_lx, t_lx+1 of row ly at bytes 0,1; of row ly+1 at 5,6; M at 4-lx
+    __builtin_memcpy(&c, p + 25, 8);  // the same one z-slice up
+    meta = __builtin_amdgcn_perm(a.y, a.x, 0x0c0c0c04u - lx);
+    uint2 r;
+    r.x = __builtin_amdgcn_perm(a.y, a.x, 0x06050100u);
+    r.y = __builtin_amdgcn_perm(c.y, c.x, 0x06050100u);
+    return r;
+}
+
 // (int)floorf(x) in one instruction (v_cvt_flr_i32_f32); identical for every in-range x.
 CT_DEV int32_t floor_to_int(float x)
 {
@@ -199,6 +231,12 @@ CT_DEV uint2 fetch_cell(const DevScene &sc, const uint8_t *bricks, f3 p, uint32_
 {
     const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
     return load_footprint_meta(sc, bricks, floor_to_int(x), floor_to_int(y), floor_to_int(z), meta);
+}
+
+CT_DEV uint2 fetch_cell_m(const DevScene &sc, f3 p, uint32_t &meta)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    return load_footprint_m(sc, floor_to_int(x), floor_to_int(y), floor_to_int(z), meta);
 }
 
 CT_DEV float filter_at(const DevScene &sc, uint2 cell, f3 p)

@@ -71,6 +71,8 @@ hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int 
                              uint8_t *dist, uint8_t *scratch, uint8_t *majorant, hipStream_t stream);
 hipError_t launch_brick_meta(const uint8_t *dist, const uint8_t *majorant, int nx, int ny, int nz, int bias, int gx,
                              int gy, int gz, uint8_t *bricks, hipStream_t stream);
+hipError_t launch_build_mbricks(const uint8_t *texels, int nx, int ny, int nz, int bias_x, int bias, int gx, int gy,
+                                int gz, uint8_t *tmp_a, uint8_t *tmp_b, uint8_t *bricks, hipStream_t stream);
 hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream);
 hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream);

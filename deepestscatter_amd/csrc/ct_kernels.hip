@@ -56,6 +56,139 @@ hipError_t launch_build_bricks(const uint8_t *texels, int nx, int ny, int nz, in
 }
 
 // =============================================================================================
+// march bricks (DevScene::mbricks): texel-granular clearance + 3x4x4 bricks with a meta byte per row
+// =============================================================================================
+constexpr int kClearMax = 127;
+
+// blocked[b] = 1 when a march step may not be skipped at base texel b: the footprint based there
+// has a non-zero texel, or b is not "interior" (1 <= b <= N-3 on every axis).
+__global__ void blocked_mask_kernel(const uint8_t *__restrict__ t, int nx, int ny, int nz, uint8_t *__restrict__ blocked)
+{
+    const int64_t total = (int64_t)nx * ny * nz;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / ((int64_t)nx * ny));
+        const bool interior = x >= 1 && y >= 1 && z >= 1 && x <= nx - 3 && y <= ny - 3 && z <= nz - 3;
+        bool b = !interior;
+        if (!b) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                m |= t[((size_t)(z + (k >> 2)) * ny + (y + ((k >> 1) & 1))) * nx + (x + (k & 1))];
+            }
+            b = m != 0;
+        }
+        blocked[i] = b ? 1 : 0;
+    }
+}
+
+// One separable pass of the capped Chebyshev distance transform along AXIS (0 x, 1 y, 2 z):
+//   pass 0: out = min |x - x'| over blocked x' of the row;
+//   pass 1, 2: out = min over k of max(k, in[.. -+ k ..]).
+// Everything outside the grid counts as blocked.  The scan walks outwards and stops at the first k
+// that cannot improve the result, so its cost is proportional to the distance found.
+template <int AXIS>
+__global__ void cheb_pass_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int nx, int ny, int nz)
+{
+    const int64_t total = (int64_t)nx * ny * nz;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / ((int64_t)nx * ny));
+        const int c = AXIS == 0 ? x : (AXIS == 1 ? y : z);
+        const int n = AXIS == 0 ? nx : (AXIS == 1 ? ny : nz);
+        const int64_t stride = AXIS == 0 ? 1 : (AXIS == 1 ? (int64_t)nx : (int64_t)nx * ny);
+        int best = kClearMax + 1;
+        for (int k = 0; k < best; k++) {
+            int v = AXIS == 0 ? (kClearMax + 1) : 0; // value at an out-of-grid neighbour: blocked
+            bool hit = false;
+            if (c - k >= 0) {
+                const int a = in[i - k * stride];
+                if (AXIS == 0) {
+                    hit = hit || a != 0;
+                } else {
+                    v = a;
+                }
+            } else {
+                hit = true;
+                v = 0;
+            }
+            int w = AXIS == 0 ? (kClearMax + 1) : 0;
+            if (c + k < n) {
+                const int a = in[i + k * stride];
+                if (AXIS == 0) {
+                    hit = hit || a != 0;
+                } else {
+                    w = a;
+                }
+            } else {
+                hit = true;
+                w = 0;
+            }
+            if (AXIS == 0) {
+                if (hit) {
+                    best = k;
+                }
+            } else {
+                best = min(best, max(k, min(v, w)));
+            }
+        }
+        out[i] = (uint8_t)min(best, kClearMax + 1);
+    }
+}
+
+// One thread per byte of the march-brick array.  dist = Chebyshev distance (texels, capped) of a
+// base texel to the nearest blocked one; a row's clearance is min over its three bases of dist-1.
+__global__ void build_mbricks_kernel(const uint8_t *__restrict__ t, const uint8_t *__restrict__ dist, int nx, int ny,
+                                     int nz, int bias_x, int bias, uint8_t *__restrict__ bricks, int gx, int gy, int gz)
+{
+    const int64_t total = (int64_t)gx * gy * gz * 128;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i >> 7;
+        const int o = (int)(i & 127);
+        uint8_t v = 0;
+        if (o < 125) {
+            const int lx = o % 5, ly = (o / 5) % 5, lz = o / 25;
+            const int x0 = (int)(b % gx) * 3 - bias_x;
+            const int y = (int)((b / gx) % gy) * 4 + ly - bias;
+            const int z = (int)(b / ((int64_t)gx * gy)) * 4 + lz - bias;
+            if (lx < 4) {
+                const int x = x0 + lx;
+                const int xc = min(max(x, 0), nx - 1), yc = min(max(y, 0), ny - 1), zc = min(max(z, 0), nz - 1);
+                v = t[((size_t)zc * ny + yc) * nx + xc];
+            } else if (ly < 4 && lz < 4) {
+                // meta byte of the base row (ly, lz): bases x0 .. x0+2
+                int c = kClearMax;
+                bool interior = true;
+                for (int k = 0; k < 3; k++) {
+                    const int x = x0 + k;
+                    const bool in_grid = x >= 0 && y >= 0 && z >= 0 && x < nx && y < ny && z < nz;
+                    const int d = in_grid ? (int)dist[((size_t)z * ny + y) * nx + x] : 0;
+                    c = min(c, d - 1);
+                    interior = interior && x >= 1 && y >= 1 && z >= 1 && x <= nx - 3 && y <= ny - 3 && z <= nz - 3;
+                }
+                v = (uint8_t)(max(c, 0) | (interior ? 0x80 : 0));
+            }
+        }
+        bricks[i] = v;
+    }
+}
+
+hipError_t launch_build_mbricks(const uint8_t *texels, int nx, int ny, int nz, int bias_x, int bias, int gx, int gy,
+                                int gz, uint8_t *tmp_a, uint8_t *tmp_b, uint8_t *bricks, hipStream_t stream)
+{
+    const int64_t texels_n = (int64_t)nx * ny * nz;
+    const int threads = 256;
+    const int tb = (int)std::min<int64_t>((texels_n + threads - 1) / threads, 65536 * 4);
+    hipLaunchKernelGGL(blocked_mask_kernel, dim3(tb), dim3(threads), 0, stream, texels, nx, ny, nz, tmp_a);
+    hipLaunchKernelGGL(cheb_pass_kernel<0>, dim3(tb), dim3(threads), 0, stream, tmp_a, tmp_b, nx, ny, nz);
+    hipLaunchKernelGGL(cheb_pass_kernel<1>, dim3(tb), dim3(threads), 0, stream, tmp_b, tmp_a, nx, ny, nz);
+    hipLaunchKernelGGL(cheb_pass_kernel<2>, dim3(tb), dim3(threads), 0, stream, tmp_a, tmp_b, nx, ny, nz);
+    const int64_t total = (int64_t)gx * gy * gz * 128;
+    const int bb = (int)std::min<int64_t>((total + threads - 1) / threads, 65536 * 4);
+    hipLaunchKernelGGL(build_mbricks_kernel, dim3(bb), dim3(threads), 0, stream, texels, tmp_b, nx, ny, nz, bias_x, bias,
+                       bricks, gx, gy, gz);
+    return hipGetLastError();
+}
+
+// =============================================================================================
 // free-space distance field over kBrick^3-texel bricks (see DevScene::dist)
 // =============================================================================================
 constexpr int kDistMax = 64;
@@ -634,8 +767,8 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 // nor leave the box; only the position updates have to be replayed (same float adds
                 // in the same order -> bit-identical path).  They still count as density lookups:
                 // the counter is the algorithm's lookup count, not the loads this kernel issued.
-                if (dfree > 1u) {
-                    const int n = (int)(((float)(kBrick * (int)(dfree - 1u)) - 0.5f) * inv_maxd);
+                if (dfree != 0u) {
+                    const int n = (int)(((float)dfree - 0.03125f) * inv_maxd);
                     for (int i = 0; i < n; i++) {
                         pos = add3(pos, stepv);
                     }
@@ -653,7 +786,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 }
                 pos = add3(pos, stepv);
                 uint32_t meta;
-                const uint2 cell = fetch_cell(sc, sc.dbricks, pos, meta);
+                const uint2 cell = fetch_cell_m(sc, pos, meta);
                 dfree = meta & 0x7fu;
                 c_dl += 1;
                 work += 1u;

@@ -291,13 +291,18 @@ class CloudTracer:
 
     def debug_stats(self) -> dict:
         """Scheduler diagnostics (only filled when the process runs with CT_STATS=1)."""
-        out = np.zeros(16, np.uint64)
+        out = np.zeros(64, np.uint64)
         check(self.L.ct_debug_stats(self.h, _p(out)), self.h)
         names = ["regen_phases", "regen_lanes", "march_phases", "march_lanes", "scatter_phases", "scatter_lanes",
                  "fetched_steps", "fetched_zero_cells", "skipped_steps", "zero_cells_nonfree_brick",
                  "zero_cells_free_brick_d1", "skip_loop_wave_iterations", "waves_xcd_eq_block_mod8", "waves",
-                 "stolen_jobs"]
-        return {n: int(v) for n, v in zip(names, out)}
+                 "stolen_jobs", "max_scheduler_visits_of_a_wave"]
+        d = {n: int(v) for n, v in zip(names, out)}
+        # waves by the time they ended (5 ms bins from their own start), and by how long they kept
+        # running after they had found the job queue empty (0.5 ms bins)
+        d["wave_end_hist_5ms"] = [int(v) for v in out[16:40]]
+        d["wave_end_minus_drained_hist_0p5ms"] = [int(v) for v in out[40:64]]
+        return d
 
     def debug_cdf_inversion(self, first_u24: int, count: int) -> np.ndarray:
         out = np.empty(count, np.uint32)

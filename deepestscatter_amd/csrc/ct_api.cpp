@@ -42,7 +42,7 @@ struct CtHandle_ {
     // work queue of the persistent kernel (rebuilt when the camera moves)
     float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
     uint32_t *d_pixels = nullptr;     // this shard's box-hitting pixels, padded to groups of 64
-    uint32_t *d_cost = nullptr;       // measured cost per group (sum of path depths)
+    uint32_t *d_cost = nullptr;       // measured per group: [0,n) sum of path costs, [n,2n) deepest path
     uint32_t *d_job_group = nullptr, *d_job_sub = nullptr; // job list of the current batch size
     uint32_t n_groups = 0, groups_capacity = 0;
     uint32_t n_jobs = 0, jobs_capacity = 0, jobs_S = 0;
@@ -289,6 +289,10 @@ static int create_impl(const CtScene *s, CtHandle h)
     h->queues_enabled = false;
     if (const char *e = getenv("CT_XCD_QUEUES")) {
         h->queues_enabled = atoi(e) != 0;
+    }
+    d.tail_burst = 1;
+    if (const char *e = getenv("CT_TAIL_BURST")) {
+        d.tail_burst = (uint32_t)std::min(1024, std::max(1, atoi(e)));
     }
     if (const char *e = getenv("CT_SHARED_DEPTH")) {
         h->shared_depth = (float)atof(e);
@@ -589,7 +593,7 @@ static int rebuild_queue(CtHandle h)
         }
         h->d_pixels = h->d_cost = nullptr;
         HIPCHK(h, dmalloc(&h->d_pixels, (size_t)h->n_groups * 64));
-        HIPCHK(h, dmalloc(&h->d_cost, h->n_groups));
+        HIPCHK(h, dmalloc(&h->d_cost, 2 * (size_t)h->n_groups));
         h->groups_capacity = h->n_groups;
     }
     h->group_order.resize(h->n_groups);
@@ -600,7 +604,7 @@ static int rebuild_queue(CtHandle h)
     if (h->n_groups) {
         HIPCHK(h, hipMemcpyAsync(h->d_pixels, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
                                  h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_cost, 0, h->n_groups * sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_cost, 0, 2 * (size_t)h->n_groups * sizeof(uint32_t), h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     h->queue_dirty = false;
@@ -710,24 +714,32 @@ static int tune_order(CtHandle h, uint32_t measured_subframes)
     if (h->n_groups < 2 || measured_subframes == 0) {
         return CT_OK;
     }
-    std::vector<uint32_t> cost(h->n_groups);
+    std::vector<uint32_t> cost(2 * (size_t)h->n_groups);
     HIPCHK(h, hipMemcpyAsync(cost.data(), h->d_cost, cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
                              h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    auto cls = [&](uint32_t g) {
-        uint32_t c = cost[g], k = 0;
+    auto log2_class = [](uint32_t c) {
+        uint32_t k = 0;
         while (c) {
             k++;
             c >>= 1;
         }
         return k;
     };
+    // Order: by the deepest path a group has produced (a launch ends when its last path does, so
+    // the groups that can produce long paths must not be the last ones running), then by mean cost.
+    const uint32_t *deepest = cost.data() + h->n_groups;
     for (uint32_t g = 0; g < h->n_groups; g++) {
         h->group_order[g] = g;
         h->group_depth[g] = (float)cost[g] / (64.f * (float)measured_subframes);
     }
-    std::stable_sort(h->group_order.begin(), h->group_order.end(),
-                     [&](uint32_t a, uint32_t b) { return cls(a) > cls(b); });
+    std::stable_sort(h->group_order.begin(), h->group_order.end(), [&](uint32_t a, uint32_t b) {
+        const uint32_t ka = log2_class(deepest[a]), kb = log2_class(deepest[b]);
+        if (ka != kb) {
+            return ka > kb;
+        }
+        return log2_class(cost[a]) > log2_class(cost[b]);
+    });
     h->jobs_S = 0; // rebuild the job list with the new order
     return CT_OK;
 }
@@ -783,6 +795,7 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
     ba.job_group = h->d_job_group;
     ba.job_sub = h->d_job_sub;
     ba.cost = h->order_tuned ? nullptr : h->d_cost;
+    ba.cost_max = h->order_tuned ? nullptr : h->d_cost + h->n_groups;
     ba.n_jobs = h->n_jobs;
     for (int x = 0; x <= kQueues + 1; x++) {
         ba.q_begin[x] = h->q_begin[x];
@@ -1217,7 +1230,7 @@ extern "C" int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumul
     return CT_OK;
 }
 
-extern "C" int ct_debug_stats(CtHandle h, uint64_t out[16])
+extern "C" int ct_debug_stats(CtHandle h, uint64_t out[64])
 {
     NEED(h);
     if (!out) {

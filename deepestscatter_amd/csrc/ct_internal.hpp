@@ -10,7 +10,7 @@ namespace ct {
 
 constexpr int kTile = 8;            // pixel tile edge: 8x8 = one wave of primary rays
 constexpr int kCounterCount = 6;    // paths, box_hits, density, inscatter, scatter, capped
-constexpr int kStatCount = 16;      // scheduler diagnostics (ct_debug_stats)
+constexpr int kStatCount = 64;      // scheduler diagnostics (ct_debug_stats)
 constexpr int kQueues = 8;          // one job queue per XCD (MI355X: 8 XCDs, each with its own L2)
 
 // One progressive batch: subframes first .. first+S-1 of the handle's own tiles.
@@ -31,6 +31,7 @@ struct BatchArgs {
     uint32_t *cost;            // per group: sum of path costs (MARCH: fetches + 4 per bounce; DELTA:
                                // bounces), feeds the next job list; NULL once
                                // the order is tuned (hundreds of waves share a group at large S)
+    uint32_t *cost_max;        // per group: deepest path seen (same life as cost)
     uint32_t n_jobs;
     // Queue x < kQueues holds jobs [q_begin[x], q_begin[x+1]): the pixel groups of one compact image
     // region, so that the waves of one XCD share that region's bricks in their L2.  Queue kQueues

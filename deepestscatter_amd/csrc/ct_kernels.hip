@@ -618,9 +618,17 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
     uint32_t c_dl = 0, c_il = 0, c_cap = 0; // per-lane tallies
     // scheduler diagnostics (STATS builds only), see ct_debug_stats
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
-    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0;
+    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0, st_iters = 0;
 
+    const unsigned long long t_start = STATS ? wall_clock64() : 0ull; // 100 MHz
+    unsigned long long t_drained = 0;
     for (;;) {
+        if (STATS) {
+            st_iters += 1;
+            if (drained && t_drained == 0) {
+                t_drained = wall_clock64();
+            }
+        }
         // ---------------- regenerate ----------------
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
@@ -633,6 +641,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                     if (STATS) {
                         st_stolen += (q_tried != 0u) ? 1u : 0u;
                     }
+
                     const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
                     job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
                     job_s0 = sub & 0xffffu;
@@ -759,7 +768,9 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             // instructions are paid once per burst, and the lanes that collide meanwhile wait for a
             // fuller scatter phase.  The burst ends early when enough lanes wait for the scatter
             // phase or for new samples, or nobody marches any more.
-            uint32_t burst = sc.march_burst;
+            // once the queue is empty nothing is left to amortise: what remains of the launch is the
+            // latency of its longest paths, so a collided lane no longer waits for a burst to end
+            uint32_t burst = drained ? sc.tail_burst : sc.march_burst;
             for (;;) {
             if (state == ST_MARCH) {
                 // Free-space skip: every brick within Chebyshev distance dfree-1 of the one `pos` is
@@ -817,6 +828,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                     ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
                     if (ba.cost) {
                         atomicAdd(&ba.cost[group], work);
+                        atomicMax(&ba.cost_max[group], depth);
                     }
                     state = ST_IDLE;
                 }
@@ -839,6 +851,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
             if (ba.cost) {
                 atomicAdd(&ba.cost[group], work);
+                atomicMax(&ba.cost_max[group], depth);
             }
             state = ST_IDLE;
         }
@@ -882,6 +895,10 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             atomicAdd(&ba.stats[12], (unsigned long long)(xcd_id() == (blockIdx.x & (uint32_t)(kQueues - 1)) ? 1u : 0u));
             atomicAdd(&ba.stats[13], 1ull);
             atomicAdd(&ba.stats[14], (unsigned long long)st_stolen);
+            atomicMax(&ba.stats[15], (unsigned long long)st_iters);
+            const unsigned long long t_end = wall_clock64();
+            atomicAdd(&ba.stats[16 + min((unsigned long long)23, (t_end - t_start) / 500000ull)], 1ull);
+            atomicAdd(&ba.stats[40 + min((unsigned long long)23, (t_end - (t_drained ? t_drained : t_end)) / 50000ull)], 1ull);
         }
     }
     if (lane == 0) {
@@ -1158,6 +1175,7 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
             ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
             if (ba.cost) {
                 atomicAdd(&ba.cost[group], depth);
+                atomicMax(&ba.cost_max[group], depth);
             }
             state = ST_IDLE;
         }

@@ -263,7 +263,7 @@ CT_API int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_
  * part of the algorithm): out[0..15] = regen phases, regen lanes, march phases, march lanes,
  * scatter phases, scatter lanes, fetched march steps, fetched steps whose 8 texels were all 0,
  * skipped (replayed) march steps, skip-loop trips (wave level), rest reserved. */
-CT_API int ct_debug_stats(CtHandle h, uint64_t out[16]);
+CT_API int ct_debug_stats(CtHandle h, uint64_t out[64]);
 
 /* PMC calibration probe (no handle): allocates 2^log2_lines 128-byte lines on `device`, and has one
  * thread per line issue the estimator's access pattern (two unaligned 8-byte loads at byte 13 and

@@ -50,7 +50,8 @@ struct CtHandle_ {
     uint64_t own_pixels = 0, hit_pixels = 0;
     bool queue_dirty = true, order_tuned = false;
     bool queues_enabled = false;         // per-XCD regions (CT_XCD_QUEUES=1; default: one global list)
-    float shared_depth = 64.f;           // groups at least this deep (bounces) use the shared queue
+    float shared_depth = 1e30f;          // groups at least this deep (bounces) use the shared queue
+    uint32_t regions = 128;              // image regions dealt to the per-XCD queues
     std::vector<uint32_t> group_order;   // groups, most expensive first (identity until tuned)
     std::vector<float> group_depth;      // measured mean path cost per group (0 until tuned), in the
                                          // units of BatchArgs::cost
@@ -273,7 +274,7 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.mode = s->mode;
     d.tiles_x = (s->width + kTile - 1) / kTile;
     d.tiles_y = (s->height + kTile - 1) / kTile;
-    d.regen_min = 8;
+    d.regen_min = 16;
     // measured: running the scatter phase as soon as any lane needs it beats waiting for a fuller
     // phase (927 vs 877 Msamples/s); a waiting lane is latency added to a serial path
     d.scatter_num = 0;
@@ -293,6 +294,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.tail_burst = 1;
     if (const char *e = getenv("CT_TAIL_BURST")) {
         d.tail_burst = (uint32_t)std::min(1024, std::max(1, atoi(e)));
+    }
+    if (const char *e = getenv("CT_XCD_REGIONS")) {
+        h->regions = (uint32_t)std::min(65536, std::max(1, atoi(e)));
     }
     if (const char *e = getenv("CT_SHARED_DEPTH")) {
         h->shared_depth = (float)atof(e);
@@ -645,7 +649,12 @@ static int build_jobs(CtHandle h, uint32_t S)
                 continue;
             }
             const double w = (double)h->group_depth[g] + unit;
-            queue_of[g] = (uint8_t)std::min<double>(nq - 1, std::floor((run + 0.5 * w) / total * nq));
+            // h->regions compact image regions of equal cost, dealt round-robin to the queues: every
+            // XCD still works on 1/8 of the image (a handful of compact pieces), and errors of the
+            // cost estimate, which are correlated in space, average out over its pieces
+            const uint32_t regions = std::max(nq, h->regions);
+            const uint32_t r = (uint32_t)std::min<double>(regions - 1, std::floor((run + 0.5 * w) / total * regions));
+            queue_of[g] = (uint8_t)(r % nq);
             run += w;
         }
     }

@@ -780,7 +780,16 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 // the counter is the algorithm's lookup count, not the loads this kernel issued.
                 if (dfree != 0u) {
                     const int n = (int)(((float)dfree - 0.03125f) * inv_maxd);
-                    for (int i = 0; i < n; i++) {
+                    // the adds are the work; a wave-level branch per add is not: blocks of 8, then singles
+                    // (measured: 1815 -> 1891 Msamples/s; 16/4/1 is no better)
+                    int i = 0;
+                    for (; i + 8 <= n; i += 8) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            pos = add3(pos, stepv);
+                        }
+                    }
+                    for (; i < n; i++) {
                         pos = add3(pos, stepv);
                     }
                     c_dl += (uint32_t)n;

@@ -131,6 +131,45 @@ def test_free_space_skipping_is_bit_exact(dims, radius):
     plain.close()
 
 
+def _speck_volume(dims, seed):
+    """Isolated non-zero texels, thin shells, a slab that touches two faces of the volume (no zero
+    border there) -- everything the clearance codes of the march bricks can get wrong."""
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = dims
+    t = np.zeros((nz, ny, nx), np.uint8)
+    specks = rng.random(t.shape) < 0.004
+    t[specks] = rng.integers(1, 256, int(specks.sum()), dtype=np.uint8)
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    r = np.sqrt((x - 0.5 * nx) ** 2 + (y - 0.45 * ny) ** 2 + (z - 0.55 * nz) ** 2)
+    t[np.abs(r - 0.30 * min(dims)) < 0.6] = 200          # one-texel shell
+    t[np.abs(r - 0.12 * min(dims)) < 1.2] = 90           # thicker inner shell
+    t[nz // 3, :, :] = np.maximum(t[nz // 3, :, :], 40)   # slab through the whole box, faces included
+    t[:, :, 0] = np.maximum(t[:, :, 0], 3)                # a non-zero face
+    return t
+
+
+@pytest.mark.parametrize("dims", [(49, 50, 52), (64, 37, 45)])
+def test_march_bricks_on_adversarial_volumes(dims):
+    """3x4x4 march bricks: x extents that are not multiples of 3, clearance codes next to isolated
+    texels and one-texel shells, non-zero texels on the faces (isInBox ends those paths, not the
+    zero border).  Radiance and the algorithm's lookup counts must equal the oracle's."""
+    tex = _speck_volume(dims, seed=77)
+    w, h = 40, 32
+    tr, orc = make_pair(tex, w, h, mode=0, cloud_size_m=900.0)
+    mean, m2 = orc.render(2)
+    tr.render_accumulate(1, 2)
+    assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2)
+    assert tr.counters() == orc.counters.as_dict()
+    for eye in ((0.3, 2.2, 0.4), (-0.4, -0.2, -2.4), (-2.3, 0.3, 0.2)):
+        U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
+        tr.set_camera(eye, U, V, W)
+        orc.set_camera(eye, U, V, W)
+        tr.render_subframe(7)
+        assert np.array_equal(tr.frame(), orc.render_subframe(7))
+    assert tr.counters() == orc.counters.as_dict()
+    tr.close()
+
+
 def test_simple_kernel_equals_persistent_kernel():
     tex = sphere_volume(32, seed=6)
     a = ds.CloudTracer(tex, width=40, height=32, mode=0)

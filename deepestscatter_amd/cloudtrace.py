@@ -215,6 +215,17 @@ class CloudTracer:
         check(self.L.ct_generate_scatter_samples(self.h, count, batch_seed & 0xFFFFFFFF, _p(pos), _p(d)), self.h)
         return pos, d
 
+    def collect_descriptors(self, positions: np.ndarray, directions: np.ndarray) -> np.ndarray:
+        """setupHierarchicalDescriptor (DisneyDescriptor.cuh:71-112) for (position, view direction) samples:
+        -> uint8 [count, 10, 9, 5, 5] (layer, z, y, x), the `grid` bytes of Persistance::DisneyDescriptor."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        if len(pos) != len(d):
+            raise ValueError("positions and directions differ in length")
+        out = np.empty((len(pos), 10, 9, 5, 5), np.uint8)
+        check(self.L.ct_collect_descriptors(self.h, _p(pos), _p(d), len(pos), _p(out)), self.h)
+        return out
+
     def reset(self):
         check(self.L.ct_reset(self.h), self.h)
 

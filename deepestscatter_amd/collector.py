@@ -185,6 +185,48 @@ def decode_scatter_sample(b: bytes):
     return sid, tuple(vecs[0x12]), tuple(vecs[0x1A])
 
 
+def encode_disney_descriptor(grid) -> bytes:
+    """Persistance::DisneyDescriptor { bytes grid = 1; }  (DisneyDescriptor.proto:7-10): the 10*9*5*5 bytes
+    DisneyDescriptorCollector::recordToDataset (DisneyDescriptorCollector.cpp:73-100) copies layer by layer."""
+    raw = np.ascontiguousarray(grid, np.uint8).tobytes()
+    if len(raw) != 2250:
+        raise ValueError("a descriptor has 10 x 9 x 5 x 5 bytes")
+    return b"\x0a" + _varint(len(raw)) + raw
+
+
+def decode_disney_descriptor(b: bytes) -> np.ndarray:
+    if not b:
+        return np.zeros((10, 9, 5, 5), np.uint8)        # proto3 omits an empty bytes field
+    if b[0] != 0x0A:
+        raise ValueError(f"unexpected tag {b[0]:#x} in DisneyDescriptor")
+    n, i = _read_varint(b, 1)
+    return np.frombuffer(b[i:i + n], np.uint8).reshape(10, 9, 5, 5).copy()
+
+
+class DisneyDescriptorCollector:
+    """Host-side mirror of the reference's DisneyDescriptorCollector (src/Scene/DisneyDescriptorCollector.cpp):
+    reads a batch of ScatterSample records (:25-41), runs `collect` once (:57-63) and serialises one
+    Persistance::DisneyDescriptor per sample (:73-100).  `collect_fn(positions, directions)` is
+    CloudTracer.collect_descriptors (ct_collect_descriptors)."""
+
+    def __init__(self, collect_fn: Callable[[np.ndarray, np.ndarray], np.ndarray], scatter_sample_records,
+                 batch_start_id: int = 0):
+        self.collect_fn = collect_fn
+        self.batch_start_id = batch_start_id
+        samples = [decode_scatter_sample(r) for r in scatter_sample_records]
+        self.positions = np.array([p for _, p, _ in samples], np.float32).reshape(-1, 3)
+        self.directions = np.array([d for _, _, d in samples], np.float32).reshape(-1, 3)
+        self.descriptors = None
+
+    def collect(self) -> None:
+        self.descriptors = self.collect_fn(self.positions, self.directions)
+
+    def results(self) -> list[tuple[int, bytes]]:
+        if self.descriptors is None:
+            self.collect()
+        return [(self.batch_start_id + i, encode_disney_descriptor(g)) for i, g in enumerate(self.descriptors)]
+
+
 def _varint(n: int) -> bytes:
     out = bytearray()
     while True:

@@ -33,6 +33,8 @@ struct CtHandle_ {
     // device memory
     uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr, *d_majorant = nullptr;
     uint8_t *d_dbricks = nullptr, *d_ibricks = nullptr, *d_mbricks = nullptr;
+    uint8_t *d_pyramid = nullptr;     // density mip pyramid, built on first use (ct_collect_descriptors)
+    MipPyramid pyramid{};
     float *d_mie = nullptr, *d_chopped = nullptr, *d_cdf = nullptr;
     uint16_t *d_guide = nullptr;
     float4 *d_frame = nullptr, *d_mean = nullptr, *d_m2 = nullptr;
@@ -191,7 +193,7 @@ static void release(CtHandle h)
     if (h->stream) {
         hipStreamSynchronize(h->stream);
     }
-    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mie, h->d_chopped, h->d_cdf,
+    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_primary, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
@@ -246,6 +248,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.hx = d.bx + 0.01f;
     d.hy = d.by + 0.01f;
     d.hz = d.bz + 0.01f;
+    d.tsx = maxs / fx;
+    d.tsy = maxs / fy;
+    d.tsz = maxs / fz;
     d.sx = (maxs / fx) * fx; // textureScale * N
     d.sy = (maxs / fy) * fy;
     d.sz = (maxs / fz) * fz;
@@ -1054,6 +1059,87 @@ extern "C" int ct_generate_scatter_samples(CtHandle h, uint32_t count, uint32_t 
         hipStreamSynchronize(h->stream);
     }
     for (void *p : { (void *)d_pos, (void *)d_dir }) {
+        if (p) {
+            hipFree(p);
+        }
+    }
+    return rc;
+}
+
+// Resources::generateMipmaps (Resources.cpp:169-209) on the device: levels = floor(log2(maxDim)) + 1.
+static int ensure_pyramid(CtHandle h)
+{
+    if (h->d_pyramid) {
+        return CT_OK;
+    }
+    const uint32_t nx = h->scene.dims[0], ny = h->scene.dims[1], nz = h->scene.dims[2];
+    uint32_t m = std::max(nx, std::max(ny, nz)), levels = 1;
+    while (m /= 2) {
+        levels++;
+    }
+    if (levels > (uint32_t)kMaxMipLevels) {
+        return fail(h, CT_E_INVAL, "volume too large for the mip pyramid");
+    }
+    MipPyramid mp{};
+    mp.levels = levels;
+    size_t total = 0;
+    for (uint32_t l = 0; l < levels; l++) {
+        mp.nx[l] = (int32_t)std::max(1u, nx >> l);
+        mp.ny[l] = (int32_t)std::max(1u, ny >> l);
+        mp.nz[l] = (int32_t)std::max(1u, nz >> l);
+        mp.offset[l] = (uint32_t)total;
+        total += (size_t)mp.nx[l] * mp.ny[l] * mp.nz[l];
+    }
+    if (total >= (1ull << 32)) {
+        return fail(h, CT_E_INVAL, "volume too large for the mip pyramid");
+    }
+    HIPCHK(h, dmalloc(&h->d_pyramid, total));
+    HIPCHK(h, hipMemcpyAsync(h->d_pyramid, h->d_density, (size_t)nx * ny * nz, hipMemcpyDeviceToDevice, h->stream));
+    for (uint32_t l = 1; l < levels; l++) {
+        HIPCHK(h, launch_mip_level(h->d_pyramid + mp.offset[l - 1], mp.nx[l - 1], mp.ny[l - 1], mp.nz[l - 1],
+                                   h->d_pyramid + mp.offset[l], mp.nx[l], mp.ny[l], mp.nz[l], h->stream));
+    }
+    mp.base = h->d_pyramid;
+    h->pyramid = mp;
+    return CT_OK;
+}
+
+extern "C" int ct_collect_descriptors(CtHandle h, const float *positions_host, const float *directions_host,
+                                      uint32_t count, uint8_t *descriptors_host_out)
+{
+    NEED(h);
+    if (!positions_host || !directions_host || !descriptors_host_out || count == 0 || count > (1u << 20)) {
+        return fail(h, CT_E_INVAL, "ct_collect_descriptors: need 1..2^20 samples, two input arrays and an output array");
+    }
+    const int prc = ensure_pyramid(h);
+    if (prc != CT_OK) {
+        return prc;
+    }
+    // VDBCloud::getVoxelSizeInMeters / getVoxelSizeInTermsOfFreePath (VDBCloud.cpp:35-46), DisneyDescriptor.cuh:83
+    const float maxs = (float)std::max(h->scene.dims[0], std::max(h->scene.dims[1], h->scene.dims[2]));
+    const float voxel_m = h->scene.cloud_size_m / maxs;
+    const float voxel_fp = voxel_m / h->scene.mean_free_path_m;
+    const float level0 = -ct_log2f(voxel_fp) - 1;
+    float *d_pos = nullptr, *d_dir = nullptr;
+    uint8_t *d_out = nullptr;
+    auto run = [&]() -> int {
+        HIPCHK(h, dmalloc(&d_pos, 3 * (size_t)count));
+        HIPCHK(h, dmalloc(&d_dir, 3 * (size_t)count));
+        HIPCHK(h, dmalloc(&d_out, (size_t)count * CT_DESCRIPTOR_BYTES));
+        HIPCHK(h, hipMemcpyAsync(d_pos, positions_host, 3 * (size_t)count * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_dir, directions_host, 3 * (size_t)count * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, launch_descriptors(h->dev, h->pyramid, d_pos, d_dir, count, level0, voxel_m, h->scene.cloud_size_m,
+                                     d_out, h->stream));
+        HIPCHK(h, hipMemcpyAsync(descriptors_host_out, d_out, (size_t)count * CT_DESCRIPTOR_BYTES, hipMemcpyDeviceToHost,
+                                 h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return CT_OK;
+    };
+    const int rc = run();
+    if (rc != CT_OK) {
+        hipStreamSynchronize(h->stream);
+    }
+    for (void *p : { (void *)d_pos, (void *)d_dir, (void *)d_out }) {
         if (p) {
             hipFree(p);
         }

@@ -82,6 +82,7 @@ struct DevScene {
     int32_t m_gx, m_gxy;     // bricks per row / per slice of mbricks (y and z use brick_gy/gz, brick_bias)
     int32_t nx, ny, nz;    // texels
     float sx, sy, sz;      // box coordinate -> texel coordinate (textureScale * N)
+    float tsx, tsy, tsz;   // textureScale = maxDim / dims (VDBCloud.cpp:105)
     float bx, by, bz;      // bboxSize          (VDBCloud.cpp:104)
     float hx, hy, hz;      // bboxSize + 0.01f  (cloud.cuh:43)
     float density_multiplier;  // VDBCloud.cpp:109

@@ -103,6 +103,19 @@ hipError_t launch_point_accumulate(const float4 *frames, uint32_t stride, void *
                                    hipStream_t stream);
 hipError_t launch_scatter_samples(const DevScene &sc, uint32_t count, uint32_t batch_seed, float *positions,
                                   float *directions, hipStream_t stream);
+// Density pyramid (Resources::generateMipmaps) and the descriptor gather.
+constexpr int kMaxMipLevels = 16;
+struct MipPyramid {
+    const uint8_t *base;               // all levels, level l at base + offset[l], [Z][Y][X]
+    uint32_t levels;
+    uint32_t offset[kMaxMipLevels];
+    int32_t nx[kMaxMipLevels], ny[kMaxMipLevels], nz[kMaxMipLevels];
+};
+hipError_t launch_mip_level(const uint8_t *prev, int px, int py, int pz, uint8_t *cur, int cx, int cy, int cz,
+                            hipStream_t stream);
+hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const float *positions, const float *directions,
+                              uint32_t count, float level0, float voxel_m, float cloud_size_m, uint8_t *out,
+                              hipStream_t stream);
 LaunchShape persistent_shape(int device);
 
 } // namespace ct

@@ -919,6 +919,120 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
 }
 
 // =============================================================================================
+// Density pyramid + hierarchical descriptor
+// =============================================================================================
+// Resources::generateMipmaps, Resources.cpp:193-203: uint16 sum of the (up to) 8 children, zero
+// outside the parent level, / 8.
+__global__ void mip_level_kernel(const uint8_t *__restrict__ prev, int px, int py, int pz, uint8_t *__restrict__ cur,
+                                 int cx, int cy, int cz)
+{
+    const int64_t total = (int64_t)cx * cy * cz;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % cx), y = (int)((i / cx) % cy), z = (int)(i / ((int64_t)cx * cy));
+        uint32_t acc = 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const int sx = 2 * x + (d & 1), sy = 2 * y + ((d >> 1) & 1), sz = 2 * z + (d >> 2);
+            if (sx < px && sy < py && sz < pz) {
+                acc += prev[((size_t)sz * py + sy) * px + sx];
+            }
+        }
+        cur[i] = (uint8_t)(acc / 8u);
+    }
+}
+
+hipError_t launch_mip_level(const uint8_t *prev, int px, int py, int pz, uint8_t *cur, int cx, int cy, int cz,
+                            hipStream_t stream)
+{
+    const int64_t total = (int64_t)cx * cy * cz;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(mip_level_kernel, dim3(blocks), dim3(256), 0, stream, prev, px, py, pz, cur, cx, cy, cz);
+    return hipGetLastError();
+}
+
+// One level of rtTex3DLod: trilinear, clamp-to-edge, x = fma(pos, textureScale * dim, -0.5).
+CT_DEV float tex3_level(const DevScene &sc, const MipPyramid &mp, uint32_t l, f3 p)
+{
+    const int32_t nx = mp.nx[l], ny = mp.ny[l], nz = mp.nz[l];
+    const float x = fmaf(p.x, sc.tsx * (float)nx, -0.5f), y = fmaf(p.y, sc.tsy * (float)ny, -0.5f),
+                z = fmaf(p.z, sc.tsz * (float)nz, -0.5f);
+    const float flx = floorf(x), fly = floorf(y), flz = floorf(z);
+    const float wx = fract_(x), wy = fract_(y), wz = fract_(z);
+    const int32_t ix = (int32_t)flx, iy = (int32_t)fly, iz = (int32_t)flz;
+    const int32_t x0 = min(max(ix, 0), nx - 1), x1 = min(max(ix + 1, 0), nx - 1);
+    const int32_t y0 = min(max(iy, 0), ny - 1), y1 = min(max(iy + 1, 0), ny - 1);
+    const int32_t z0 = min(max(iz, 0), nz - 1), z1 = min(max(iz + 1, 0), nz - 1);
+    const uint8_t *b = mp.base + mp.offset[l];
+    const size_t sy_ = (size_t)nx, sz_ = (size_t)nx * (size_t)ny;
+    uint2 c;
+    c.x = (uint32_t)b[z0 * sz_ + y0 * sy_ + x0] | ((uint32_t)b[z0 * sz_ + y0 * sy_ + x1] << 8) |
+          ((uint32_t)b[z0 * sz_ + y1 * sy_ + x0] << 16) | ((uint32_t)b[z0 * sz_ + y1 * sy_ + x1] << 24);
+    c.y = (uint32_t)b[z1 * sz_ + y0 * sy_ + x0] | ((uint32_t)b[z1 * sz_ + y0 * sy_ + x1] << 8) |
+          ((uint32_t)b[z1 * sz_ + y1 * sy_ + x0] << 16) | ((uint32_t)b[z1 * sz_ + y1 * sy_ + x1] << 24);
+    return filter_cell(c, wx, wy, wz);
+}
+
+// setupHierarchicalDescriptor, DisneyDescriptor.cuh:71-112.  One block per (sample, layer), one thread
+// per grid point: the 225 points of a layer touch neighbouring texels of one or two pyramid levels.
+__global__ __launch_bounds__(256) void descriptor_kernel(DevScene sc, MipPyramid mp, const float *__restrict__ positions,
+                                                         const float *__restrict__ directions, uint32_t count,
+                                                         float level0, float voxel_m, float cloud_size_m,
+                                                         uint8_t *__restrict__ out)
+{
+    const uint32_t layer = blockIdx.x % 10u, i = blockIdx.x / 10u;
+    const uint32_t sample = threadIdx.x;
+    if (i >= count || sample >= 225u) {
+        return;
+    }
+    const f3 world = mk3(positions[3 * (size_t)i], positions[3 * (size_t)i + 1], positions[3 * (size_t)i + 2]);
+    const f3 view = mk3(directions[3 * (size_t)i], directions[3 * (size_t)i + 1], directions[3 * (size_t)i + 2]);
+    const f3 ez = normalize3(mk3(sc.nlx, sc.nly, sc.nlz)); // normalize(-lightDirection), :76
+    const f3 ex = normalize3(cross3(ez, view));
+    const f3 ey = cross3(ex, ez);
+    const f3 origin = add3(world, scale3(mk3(sc.bx, sc.by, sc.bz), 0.5f));
+    float scale = 0.5f / sc.density_multiplier;
+    float lod = level0;
+    for (uint32_t l = 0; l < layer; l++) { // the same float operations as the reference's layer loop
+        scale *= 2;
+        lod += 1;
+    }
+    const float mip_voxel = ct_powf(2.0f, lod) * voxel_m / cloud_size_m;
+    const int x = (int)(sample % 5u) - 2, y = (int)((sample / 5u) % 5u) - 2, z = (int)(sample / 25u) - 2;
+    const f3 dir = add3(add3(scale3(ex, (float)x), scale3(ey, (float)y)), scale3(ez, (float)z));
+    const f3 pos = add3(origin, scale3(dir, scale));
+    // rtTex3DLod, mip-linear
+    float lc = fminf(fmaxf(0.0f, lod), (float)(mp.levels - 1u));
+    const float fl = floorf(lc);
+    const uint32_t l0 = (uint32_t)fl;
+    const float w = lc - fl;
+    float density = tex3_level(sc, mp, l0, pos);
+    if (w > 0.0f) {
+        const float s1 = tex3_level(sc, mp, min(l0 + 1u, mp.levels - 1u), pos);
+        density = fmaf(w, s1 - density, density);
+    }
+    // distanceToBox, :47-55
+    const f3 half = scale3(mk3(sc.bx, sc.by, sc.bz), 0.5f);
+    f3 dist = sub3(pos, half);
+    dist = mk3(fabsf(dist.x), fabsf(dist.y), fabsf(dist.z));
+    const float hv = mip_voxel * 0.5f;
+    dist = sub3(dist, mk3(fmaxf(half.x - hv, 0.f), fmaxf(half.y - hv, 0.f), fmaxf(half.z - hv, 0.f)));
+    dist = mk3(fmaxf(dist.x, 0.f), fmaxf(dist.y, 0.f), fmaxf(dist.z, 0.f));
+    const float distance = sqrtf(dot3(dist, dist));
+    const float t = fminf(fmaxf(distance / mip_voxel, 0.0f), 1.0f);
+    density = density + t * (0.0f - density);
+    out[((size_t)i * 10u + layer) * 225u + sample] = (uint8_t)(density * 255.0f);
+}
+
+hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const float *positions, const float *directions,
+                              uint32_t count, float level0, float voxel_m, float cloud_size_m, uint8_t *out,
+                              hipStream_t stream)
+{
+    hipLaunchKernelGGL(descriptor_kernel, dim3(count * 10u), dim3(256), 0, stream, sc, mp, positions, directions, count,
+                       level0, voxel_m, cloud_size_m, out);
+    return hipGetLastError();
+}
+
+// =============================================================================================
 // DELTA estimator: Woodcock tracking over the brick majorants (BASELINE.json north_star; not the
 // reference's sampler -- the oracle twin is delta_flight() in oracle/ct_oracle.c, whose header
 // states the algorithm).  Same persistent wave scheduler; the "march" phase becomes one tracking

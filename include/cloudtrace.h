@@ -230,6 +230,22 @@ CT_API int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_host,
 CT_API int ct_generate_scatter_samples(CtHandle h, uint32_t count, uint32_t batch_seed,
                                        float *positions_host_out, float *directions_host_out);
 
+/* setupHierarchicalDescriptor<DisneyDescriptor, uint8_t> (src/CUDA/DisneyDescriptor.cuh:71-112) as launched
+ * by DisneyDescriptorCollector::collect (src/Scene/DisneyDescriptorCollector.cpp:57-63; program `collect`,
+ * src/CUDA/disneyDescriptorCollector.cu:21-28): for every (position, view direction) sample, 10 layers of
+ * 9 x 5 x 5 trilinear + mip-linear samples of the density pyramid (Resources::generateMipmaps,
+ * Resources.cpp:169-209) in the frame eZ = -light, eX = normalize(eZ x view), eY = eX x eZ; layer l spans
+ * [-1,1]^2 x [-1,3] * 2^l free paths at LOD level0 + l, faded to zero outside the box, stored as uint8
+ * (f * 255, truncating).  positions are the ScatterSample records' `point` (world coordinates, box centred
+ * at 0); both inputs are host arrays of 3*count floats; descriptors_host_out receives
+ * count * CT_DESCRIPTOR_BYTES bytes, layer-major, then z, y, x -- the `grid` field of
+ * Persistance::DisneyDescriptor (DeepestScatter_Train/Protocols/DisneyDescriptor.proto:7-10). */
+#define CT_DESCRIPTOR_LAYERS 10
+#define CT_DESCRIPTOR_LAYER_SIZE 225
+#define CT_DESCRIPTOR_BYTES (CT_DESCRIPTOR_LAYERS * CT_DESCRIPTOR_LAYER_SIZE)
+CT_API int ct_collect_descriptors(CtHandle h, const float *positions_host, const float *directions_host,
+                                  uint32_t count, uint8_t *descriptors_host_out);
+
 /* ---- data access -------------------------------------------------------------------- */
 
 /* BufferBind<T>(buffer) map/copy, src/Util/BufferBind.h:11-74 (e.g. Camera.cpp:161,239-240).

@@ -112,6 +112,12 @@ CT_FN float ct_logf(float x)
 
 /* x^y for x >= 0 as exp(y*log x); x == 0 -> 0 (y > 0 assumed).
  * Only used by the display tonemap (reinhard.cu:74-76). */
+/* log2(x) = ln(x) * (1/ln 2), one extra rounding (used for mip levels only) */
+CT_FN float ct_log2f(float x)
+{
+    return ct_logf(x) * 1.44269504088896341f;
+}
+
 CT_FN float ct_powf(float x, float y)
 {
     if (!(x > 0.0f)) {

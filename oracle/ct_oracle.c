@@ -698,6 +698,130 @@ ORC_API void orc_generate_scatter_samples(const OrcScene *s, uint32_t count, uin
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Hierarchical descriptor: setupHierarchicalDescriptor<DisneyDescriptor, uint8_t>
+ * (src/CUDA/DisneyDescriptor.cuh:71-112) launched by DisneyDescriptorCollector::collect
+ * (src/Scene/DisneyDescriptorCollector.cpp:57-63, program src/CUDA/disneyDescriptorCollector.cu:21-28).
+ * 10 layers x (9 x 5 x 5) samples of the density PYRAMID (Resources.cpp:169-209) in the frame
+ * (eX, eY, eZ = -light), layer support doubling, LOD rising by one per layer, faded to zero
+ * outside the box, stored as uint8 (TFromFloat<uint8_t>: f * 255, truncating).
+ *
+ * rtTex3DLod with RT_FILTER_LINEAR for min/mag/mip (VDBCloud.cpp:128-132), restated like the
+ * level-0 sampler of this file: lod clamped to [0, levels-1]; l0 = floor(lod), w = lod - l0;
+ * each level trilinear with x = fma(pos, textureScale * dim_l, -0.5), clamp-to-edge;
+ * result = fma(w, s1 - s0, s0) (s0 alone when w == 0).
+ * ------------------------------------------------------------------------------------------ */
+#define ORC_DESC_LAYERS 10
+ORC_API uint32_t orc_mip_levels(const uint32_t dims[3]);
+ORC_API size_t orc_generate_mipmaps(const uint8_t *level0, const uint32_t dims[3], uint8_t *out);
+static inline uint32_t mip_dim_fwd(uint32_t d, uint32_t level)
+{
+    const uint32_t v = d >> level;
+    return v ? v : 1;
+}
+#define ORC_DESC_LAYER_SIZE 225
+
+static float tex3_lod(const Ctx *c, const uint8_t *pyramid, const size_t *offsets, const uint32_t dims[3],
+                      uint32_t levels, v3 pos, float lod)
+{
+    lod = fmaxf(0.0f, lod);
+    lod = fminf(lod, (float)(levels - 1));
+    const float fl = floorf(lod);
+    const uint32_t l0 = (uint32_t)fl;
+    const float w = lod - fl;
+    float s[2] = { 0.f, 0.f };
+    for (uint32_t k = 0; k < 2; k++) {
+        if (k == 1 && !(w > 0.0f)) {
+            break;
+        }
+        uint32_t l = l0 + k;
+        if (l > levels - 1) {
+            l = levels - 1;
+        }
+        Tex3 t;
+        t.texels = pyramid + offsets[l];
+        t.nx = (int32_t)mip_dim_fwd(dims[0], l);
+        t.ny = (int32_t)mip_dim_fwd(dims[1], l);
+        t.nz = (int32_t)mip_dim_fwd(dims[2], l);
+        t.sx = c->tscale.x * (float)t.nx;
+        t.sy = c->tscale.y * (float)t.ny;
+        t.sz = c->tscale.z * (float)t.nz;
+        s[k] = tex3_fetch(&t, pos);
+    }
+    if (!(w > 0.0f)) {
+        return s[0];
+    }
+    return fmaf(w, s[1] - s[0], s[0]);
+}
+
+static float distance_to_box(const Ctx *c, v3 pos, float voxel_size)
+{
+    /* DisneyDescriptor.cuh:47-55 */
+    const v3 half = v3_scale(c->bbox, 0.5f);
+    v3 dist = v3_sub(pos, half);
+    dist = v3_make(fabsf(dist.x), fabsf(dist.y), fabsf(dist.z));
+    const float hv = voxel_size * 0.5f;
+    const v3 corner = v3_make(fmaxf(half.x - hv, 0.f), fmaxf(half.y - hv, 0.f), fmaxf(half.z - hv, 0.f));
+    dist = v3_sub(dist, corner);
+    dist = v3_make(fmaxf(dist.x, 0.f), fmaxf(dist.y, 0.f), fmaxf(dist.z, 0.f));
+    return sqrtf(v3_dot(dist, dist));
+}
+
+/* positions are "world" positions as the ScatterSample records hold them (box centred at 0);
+ * out: count x 10 x 225 bytes, layer-major, then z (9), y (5), x (5). */
+ORC_API void orc_collect_descriptors(const OrcScene *s, const float *positions, const float *directions,
+                                     uint32_t count, uint8_t *out)
+{
+    Ctx c;
+    ctx_init(&c, s);
+    const uint32_t levels = orc_mip_levels(s->dims);
+    size_t total = 0, offsets[32];
+    for (uint32_t l = 0; l < levels; l++) {
+        offsets[l] = total;
+        total += (size_t)mip_dim_fwd(s->dims[0], l) * mip_dim_fwd(s->dims[1], l) * mip_dim_fwd(s->dims[2], l);
+    }
+    uint8_t *pyramid = (uint8_t *)malloc(total);
+    orc_generate_mipmaps(s->density, s->dims, pyramid);
+    const float fx = (float)s->dims[0], fy = (float)s->dims[1], fz = (float)s->dims[2];
+    const float maxs = fmaxf(fmaxf(fx, fy), fz);
+    const float voxel_m = s->cloud_size_m / maxs;                 /* VDBCloud.cpp:35-41 */
+    const float voxel_fp = voxel_m / s->mean_free_path_m;         /* VDBCloud.cpp:43-46 */
+    const float level0 = -ct_log2f(voxel_fp) - 1;                 /* DisneyDescriptor.cuh:83 */
+    const v3 ez = v3_normalize(v3_neg(c.light_dir));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t ii = 0; ii < (int64_t)count; ii++) {
+        const v3 world = v3_make(positions[3 * ii], positions[3 * ii + 1], positions[3 * ii + 2]);
+        const v3 view = v3_make(directions[3 * ii], directions[3 * ii + 1], directions[3 * ii + 2]);
+        const v3 ex = v3_normalize(v3_cross(ez, view));
+        const v3 ey = v3_cross(ex, ez);
+        const v3 origin = v3_add(world, v3_scale(c.bbox, 0.5f));
+        float scale = 0.5f / c.density_multiplier;
+        float lod = level0;
+        uint8_t *o = out + (size_t)ii * ORC_DESC_LAYERS * ORC_DESC_LAYER_SIZE;
+        for (int layer = 0; layer < ORC_DESC_LAYERS; layer++) {
+            const float mip_voxel = ct_powf(2.0f, lod) * voxel_m / s->cloud_size_m;
+            int sample = 0;
+            for (int z = -2; z <= 6; z++) {
+                for (int y = -2; y <= 2; y++) {
+                    for (int x = -2; x <= 2; x++) {
+                        const v3 dir = v3_add(v3_add(v3_scale(ex, (float)x), v3_scale(ey, (float)y)), v3_scale(ez, (float)z));
+                        const v3 pos = v3_add(origin, v3_scale(dir, scale));
+                        float density = tex3_lod(&c, pyramid, offsets, s->dims, levels, pos, lod);
+                        const float distance = distance_to_box(&c, pos, mip_voxel);
+                        const float t = fminf(fmaxf(distance / mip_voxel, 0.0f), 1.0f); /* saturate */
+                        density = density + t * (0.0f - density);                      /* optix lerp */
+                        o[layer * ORC_DESC_LAYER_SIZE + sample] = (uint8_t)(density * 255.0f);
+                        sample++;
+                    }
+                }
+            }
+            scale *= 2;
+            lod += 1;
+        }
+    }
+    free(pyramid);
+}
+
 /* Gpu::PointRadianceTask (src/CUDA/PointRadianceTask.h:12-78), 40 bytes. */
 typedef struct OrcPointTask {
     int32_t id;

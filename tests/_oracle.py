@@ -124,6 +124,8 @@ def lib(fast: bool = False):
     L.orc_majorant_grid.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
     L.orc_build_majorants.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.orc_generate_scatter_samples.argtypes = [C.POINTER(OrcScene), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.orc_collect_descriptors.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.orc_collect_descriptors.restype = None
     L.orc_point_task_merge.restype = C.c_int32
     L.orc_point_task_merge.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_camera_variables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
@@ -285,6 +287,13 @@ class Oracle:
         d = np.empty((count, 3), np.float32)
         self.L.orc_generate_scatter_samples(C.byref(self.scene), count, batch_seed, _ptr(pos), _ptr(d))
         return pos, d
+
+    def collect_descriptors(self, positions: np.ndarray, directions: np.ndarray) -> np.ndarray:
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        out = np.empty((len(pos), 10, 9, 5, 5), np.uint8)
+        self.L.orc_collect_descriptors(C.byref(self.scene), _ptr(pos), _ptr(d), len(pos), _ptr(out))
+        return out
 
     def point_radiance_launch(self, tasks: np.ndarray, first_frame: int, launches: int) -> np.ndarray:
         """Oracle twin of ct_point_radiance_launch; `tasks` has the 40-byte PointRadianceTask layout."""

@@ -182,3 +182,23 @@ def test_scatter_sample_generator_bit_exact_on_gpu():
     recs = [(i, col.encode_scatter_sample(3, gp[i], gd[i])) for i in range(len(gp))]
     assert col.decode_scatter_sample(recs[5][1])[0] == 3
     tr.close()
+
+
+def test_disney_descriptor_collector_with_oracle_backend():
+    """DisneyDescriptorCollector host logic + Persistance::DisneyDescriptor wire format, the oracle as device."""
+    import _oracle as O
+    from conftest import sphere_volume
+    tex = sphere_volume(24, seed=3)
+    orc = O.Oracle(tex, 8, 8, cloud_size_m=700.0)
+    pos, view = orc.generate_scatter_samples(6, batch_seed=2)
+    records = [col.encode_scatter_sample(4, p, d) for p, d in zip(pos, view)]
+    c = col.DisneyDescriptorCollector(orc.collect_descriptors, records, batch_start_id=4 * 2048)
+    out = c.results()
+    assert [rid for rid, _ in out] == [4 * 2048 + i for i in range(6)]
+    want = orc.collect_descriptors(pos, view)
+    for (rid, blob), w in zip(out, want):
+        assert len(blob) == 1 + 2 + 2250                 # tag, 2-byte varint length, payload
+        assert blob[:3] == b"\x0a\xca\x11"
+        assert np.array_equal(col.decode_disney_descriptor(blob), w)
+    with pytest.raises(ValueError):
+        col.encode_disney_descriptor(np.zeros(7, np.uint8))

@@ -409,6 +409,28 @@ def test_delta_agrees_with_march_statistically():
     assert np.all(np.abs(b1 - b0) <= 4 * se + 0.02 * np.maximum(b0, 1e-3)), (np.abs(b1 - b0) / (se + 1e-12)).max()
 
 
+def test_descriptors_bit_exact_vs_oracle():
+    """ct_collect_descriptors (setupHierarchicalDescriptor, DisneyDescriptor.cuh:71-112): the mip pyramid,
+    the mip-linear trilinear sampler, the light/view frame and the fade outside the box, byte for byte."""
+    for dims, size_m in (((40, 40, 40), 700.0), ((36, 52, 44), 3000.0), ((64, 64, 64), 7000.0)):
+        tex = sphere_volume(dims=dims, seed=31)
+        tr, orc = make_pair(tex, 8, 8, cloud_size_m=size_m)
+        pos, view = tr.generate_scatter_samples(48, batch_seed=5)
+        rng = np.random.default_rng(9)
+        # plus points near / on / outside the faces and a view direction (anti)parallel-ish to the light
+        extra = rng.uniform(-0.75, 0.75, (16, 3)).astype(np.float32)
+        extra_v = rng.normal(size=(16, 3)).astype(np.float32)
+        extra_v /= np.linalg.norm(extra_v, axis=1, keepdims=True)
+        pos = np.concatenate([pos, extra])
+        view = np.concatenate([view, extra_v])
+        got = tr.collect_descriptors(pos, view)
+        want = orc.collect_descriptors(pos, view)
+        assert got.shape == (64, 10, 9, 5, 5)
+        assert np.array_equal(got, want)
+        assert got.any()
+        tr.close()
+
+
 def test_golden_fixture_on_gpu():
     from test_golden import load_golden
     g = load_golden()

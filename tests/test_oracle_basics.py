@@ -298,3 +298,37 @@ def test_single_scatter_homogeneous_slab_closed_form():
     K = 1e6 * float(o.derived_uniforms()[13])
     expect = K * phase * (1 - np.exp(-2 * sigma * L)) / 2 * np.exp(-sigma * 0.5 / n)
     assert abs(got / expect - 1) < 0.04, (got, expect)
+
+
+def test_descriptor_known_answers():
+    """orc_collect_descriptors (DisneyDescriptor.cuh:71-112) on volumes with closed-form answers."""
+    n = 32
+    # empty volume -> all zero
+    z = O.Oracle(np.zeros((n, n, n), np.uint8), 8, 8)
+    d0 = z.collect_descriptors([[0, 0, 0]], [[0, 0, 1]])
+    assert d0.shape == (1, 10, 9, 5, 5) and not d0.any()
+    # constant volume (no zero border): every sample inside the box reads v/255 at every LOD
+    # -> byte trunc(v/255 * 255); far outside the box the fade takes it to 0
+    full = np.full((n, n, n), 200, np.uint8)
+    f = O.Oracle(full, 8, 8, cloud_size_m=320.0)   # voxel = 10 m = 1 free path: level0 = -1 -> clamped to 0
+    d1 = f.collect_descriptors([[0, 0, 0]], [[1, 0, 0]])[0]
+    inner = d1[0]                                    # layer 0 spans +-2*0.5/32 box units around the centre
+    assert inner.min() >= 199 and inner.max() <= 200
+    assert d1[9].min() == 0                          # the outermost layer (support x512) leaves the box
+    # mip pyramid means: a level-3 texel of the constant volume is still 200
+    # linearity of the fade: a point on the box face keeps the full value, one mip voxel outside has 0
+    half = 0.5
+    p_out = [[half + 3.0 / n, 0, 0]]
+    d2 = f.collect_descriptors(p_out, [[0, 1, 0]])[0]
+    assert d2[0, 2, 2, 2] == 0                       # centre sample of layer 0 sits 3 voxels outside
+    # the frame: eZ = -light.  With the default "Side" light the +z samples move against the light;
+    # a volume filled only on the light-facing half must light up that half of the z axis
+    tex = np.zeros((n, n, n), np.uint8)
+    o = O.Oracle(tex, 8, 8, light_direction=(0, 0, 1), cloud_size_m=320.0)
+    tex2 = tex.copy()
+    tex2[: n // 2 - 2] = 255                         # z < centre  <=> towards -light (eZ = (0,0,-1))
+    o2 = O.Oracle(tex2, 8, 8, light_direction=(0, 0, 1), cloud_size_m=320.0)
+    d3 = o2.collect_descriptors([[0, 0, 0]], [[1, 0, 0]])[0]
+    # layer 1: one texel per grid step at LOD 0; z index 8 = +6*eZ = 6 texels towards -z, index 0 = 2 towards +z
+    assert d3[1, 8].min() >= 254 and d3[1, 0].max() == 0
+    assert not o.collect_descriptors([[0, 0, 0]], [[1, 0, 0]]).any()

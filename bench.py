@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a box with one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--sync-steps", action="store_true",
+                    help="wait for every step before enqueuing the next (no overlap of a launch's tail with the "
+                         "next launch)")
     return ap.parse_args()
 
 
@@ -126,10 +129,16 @@ def main():
 
     def step(first):
         # estimator + accumulate on this rank's tiles, then (N>1) the RCCL SUM-reduce of the W*H float4
-        # radiance buffer to rank 0: tiles are disjoint, so the sum is an exact merge
-        st.step(first, S)
+        # radiance buffer to rank 0: tiles are disjoint, so the sum is an exact merge.  Steps are enqueued
+        # (--sync-steps: waited for one by one): the estimator launch of step k+1 starts on a second HIP
+        # stream while the last long paths of step k finish; accumulate, copy and reduce stay in order.
+        if args.sync_steps:
+            st.step(first, S)
+        else:
+            st.step_async(first, S)
 
     def fence():
+        st.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -208,6 +217,7 @@ def main():
                         f"{('MARCH (reference-faithful)', 'DELTA (Woodcock, brick majorants)')[args.estimator]}, max_depth 2000",
             "volume": args.volume, "width": W, "height": H, "spp_per_step": S,
             "parallelism": f"pixel-tile shard x{world}" + (" + RCCL reduce of the radiance buffer" if world > 1 else ""),
+            "pipelined_steps": not args.sync_steps,
         },
         "roofline": roofline,
         "setup_s": setup_s,

@@ -201,6 +201,13 @@ class CloudTracer:
     def render_accumulate(self, first_subframe_id: int, count: int):
         check(self.L.ct_render_accumulate(self.h, first_subframe_id, count), self.h)
 
+    def render_accumulate_async(self, first_subframe_id: int, count: int):
+        """Enqueue a batch and return; up to two batches are in flight (ct_render_accumulate_async)."""
+        check(self.L.ct_render_accumulate_async(self.h, first_subframe_id, count), self.h)
+
+    def synchronize(self):
+        check(self.L.ct_synchronize(self.h), self.h)
+
     def point_radiance_launch(self, tasks: np.ndarray, first_frame_id: int, launches: int) -> np.ndarray:
         """`launches` launches of estimateEmission (pointEmissionCamera.cu:20-40) over `tasks`
         (POINT_TASK_DTYPE), updated in place and returned."""
@@ -271,6 +278,10 @@ class CloudTracer:
     def copy_to_device(self, which: int, dst_dev_ptr: int, nbytes: int):
         """D2D copy of a handle buffer into caller-owned device memory (e.g. a torch tensor)."""
         check(self.L.ct_copy_to_device(self.h, which, C.c_void_p(dst_dev_ptr), nbytes), self.h)
+
+    def copy_to_device_async(self, which: int, dst_dev_ptr: int, nbytes: int):
+        """The same, enqueued on the handle's stream behind the accumulate kernels, not waited for."""
+        check(self.L.ct_copy_to_device_async(self.h, which, C.c_void_p(dst_dev_ptr), nbytes), self.h)
 
     def device_ptr(self, which: int) -> int:
         p = C.c_void_p()

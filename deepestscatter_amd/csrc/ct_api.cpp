@@ -39,8 +39,20 @@ struct CtHandle_ {
     uint16_t *d_guide = nullptr;
     float4 *d_frame = nullptr, *d_mean = nullptr, *d_m2 = nullptr;
     uchar4 *d_screen = nullptr;
-    float4 *d_frames = nullptr; // batch scratch [S][stride] (compact) or [S][H][W] (simple kernel)
-    size_t frames_capacity = 0; // in float4
+    // Two batches may be in flight (ct_render_accumulate_async): batch k+1's estimator kernel starts on
+    // its slot's stream while the last long paths of batch k are still running; the accumulate kernels
+    // stay in subframe order on the main stream.  A slot owns what a launch writes: the per-sample
+    // scratch [S][stride] (compact) or [S][H][W] (simple kernel) and the queue counters.
+    struct Slot {
+        float4 *frames = nullptr;
+        size_t capacity = 0; // in float4
+        uint32_t *queue = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_done = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr;
+        bool pending = false, accumulated = false;
+    };
+    Slot slots[2];
+    int next_slot = 0;
     // work queue of the persistent kernel (rebuilt when the camera moves)
     float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
     uint32_t *d_pixels = nullptr;     // this shard's box-hitting pixels, padded to groups of 64
@@ -96,13 +108,25 @@ static int fail(CtHandle h, int code, const char *fmt, ...)
         }                                                                                            \
     } while (0)
 
-#define NEED(h)                                        \
+static int flush(CtHandle h);
+
+#define NEED_NOFLUSH(h)                                \
     do {                                               \
         if (!(h)) {                                    \
             return fail(nullptr, CT_E_INVAL, "null handle"); \
         }                                              \
         if (hipSetDevice((h)->device) != hipSuccess) { \
             return fail((h), CT_E_HIP, "hipSetDevice(%d) failed", (h)->device); \
+        }                                              \
+    } while (0)
+
+// Every entry point except the *_async ones first waits for the batches in flight.
+#define NEED(h)                                        \
+    do {                                               \
+        NEED_NOFLUSH(h);                               \
+        const int rc_flush_ = flush(h);                \
+        if (rc_flush_ != CT_OK) {                      \
+            return rc_flush_;                          \
         }                                              \
     } while (0)
 
@@ -190,11 +214,16 @@ static void release(CtHandle h)
         return;
     }
     hipSetDevice(h->device);
+    for (auto &sl : h->slots) {
+        if (sl.stream) {
+            hipStreamSynchronize(sl.stream);
+        }
+    }
     if (h->stream) {
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames, h->d_primary, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->slots[0].frames, h->slots[1].frames, h->slots[0].queue, h->slots[1].queue, h->d_primary, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
         if (p) {
@@ -204,6 +233,16 @@ static void release(CtHandle h)
     for (auto &e : h->ev) {
         if (e) {
             hipEventDestroy(e);
+        }
+    }
+    for (auto &sl : h->slots) {
+        for (hipEvent_t e : { sl.ev_in, sl.ev_start, sl.ev_done, sl.ev_acc0, sl.ev_acc1 }) {
+            if (e) {
+                hipEventDestroy(e);
+            }
+        }
+        if (sl.stream) {
+            hipStreamDestroy(sl.stream);
         }
     }
     if (h->own_stream) {
@@ -433,6 +472,13 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, dmalloc(&h->d_colsum, s->width));
     HIPCHK(h, dmalloc(&h->d_avg, 1));
     HIPCHK(h, dmalloc(&h->d_queue, kQueues + 1));
+    for (auto &sl : h->slots) {
+        HIPCHK(h, dmalloc(&sl.queue, kQueues + 1));
+        HIPCHK(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        for (hipEvent_t *e : { &sl.ev_in, &sl.ev_start, &sl.ev_done, &sl.ev_acc0, &sl.ev_acc1 }) {
+            HIPCHK(h, hipEventCreate(e));
+        }
+    }
     HIPCHK(h, dmalloc(&h->d_counters, kCounterCount + 1 + kStatCount));
     HIPCHK(h, hipMemsetAsync(h->d_frame, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_mean, 0, pixels * sizeof(float4), h->stream));
@@ -767,39 +813,59 @@ static size_t frame_stride(CtHandle h)
     return (size_t)h->n_groups * 64;
 }
 
-static int ensure_frames(CtHandle h, uint32_t S)
+static int ensure_frames(CtHandle h, CtHandle_::Slot &sl, uint32_t S)
 {
     const size_t need = std::max<size_t>((size_t)S * frame_stride(h), 1);
-    if (need <= h->frames_capacity) {
+    if (need <= sl.capacity) {
         return CT_OK;
     }
-    if (h->d_frames) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipFree(h->d_frames));
-        h->d_frames = nullptr;
-        h->frames_capacity = 0;
+    if (sl.frames) {
+        HIPCHK(h, hipFree(sl.frames));
+        sl.frames = nullptr;
+        sl.capacity = 0;
     }
-    HIPCHK(h, dmalloc(&h->d_frames, need));
-    h->frames_capacity = need;
+    HIPCHK(h, dmalloc(&sl.frames, need));
+    sl.capacity = need;
     return CT_OK;
 }
 
-// One launch of the estimator over S subframes into `frames` (+ optional accumulate).
-static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, bool accumulate)
+// Waits for one slot's batch (estimator + accumulate) and books its kernel times.
+static int collect(CtHandle h, CtHandle_::Slot &sl)
+{
+    if (!sl.pending) {
+        return CT_OK;
+    }
+    sl.pending = false;
+    HIPCHK(h, hipEventSynchronize(sl.accumulated ? sl.ev_acc1 : sl.ev_done));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_start, sl.ev_done));
+    h->render_ms += ms;
+    if (sl.accumulated) {
+        HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_acc0, sl.ev_acc1));
+        h->accum_ms += ms;
+    }
+    h->launches += 1;
+    return CT_OK;
+}
+
+// Every batch in flight has finished when this returns (oldest first).
+static int flush(CtHandle h)
+{
+    for (int k = 0; k < 2; k++) {
+        const int rc = collect(h, h->slots[(h->next_slot + k) & 1]);
+        if (rc != CT_OK) {
+            return rc;
+        }
+    }
+    return CT_OK;
+}
+
+// Enqueues one launch of the estimator over S subframes into `frames` (the slot's scratch, or the
+// dense frame buffer for ct_render_subframe) on the slot's stream, and the accumulate kernel on the
+// main stream behind it.  Does not wait.
+static int submit_batch(CtHandle h, CtHandle_::Slot &sl, float4 *frames, uint32_t first, uint32_t S, bool accumulate)
 {
     const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
-    if (!simple && h->queue_dirty) {
-        const int rc = rebuild_queue(h);
-        if (rc != CT_OK) {
-            return rc;
-        }
-    }
-    if (!simple) {
-        const int rc = build_jobs(h, S);
-        if (rc != CT_OK) {
-            return rc;
-        }
-    }
     const bool dense = (frames == h->d_frame);
     BatchArgs ba{};
     ba.frames = frames;
@@ -816,32 +882,42 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
     }
     ba.first_subframe = first;
     ba.S = S;
-    ba.queue = h->d_queue;
+    ba.queue = sl.queue;
     ba.counters = h->d_counters;
     ba.stats = h->d_counters + kCounterCount + 1;
-    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, (kQueues + 1) * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    if (dense) {
+        // ct_render_subframe: the main stream has just initialised the frame buffer.  (Batches into a
+        // slot's own scratch must NOT wait for the main stream: that is where the previous batch's
+        // accumulate kernel sits, behind the previous estimator launch.)
+        HIPCHK(h, hipEventRecord(sl.ev_in, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(sl.stream, sl.ev_in, 0));
+    }
+    HIPCHK(h, hipMemsetAsync(sl.queue, 0, (kQueues + 1) * sizeof(uint32_t), sl.stream));
+    HIPCHK(h, hipEventRecord(sl.ev_start, sl.stream));
     if (simple) {
         for (uint32_t s = 0; s < S; s++) {
             BatchArgs one = ba;
             one.frames = frames + (size_t)s * h->scene.width * h->scene.height;
             one.first_subframe = first + s;
             one.S = 1;
-            HIPCHK(h, launch_render_simple(h->dev, one, h->scene.shard_index, h->scene.shard_count, h->stream));
+            HIPCHK(h, launch_render_simple(h->dev, one, h->scene.shard_index, h->scene.shard_count, sl.stream));
         }
     } else {
         if (h->n_jobs != 0) {
             if (h->scene.estimator == CT_EST_DELTA) {
-                HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
+                HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, sl.stream));
             } else {
-                HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+                HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, sl.stream));
             }
         }
         h->host_paths += h->own_pixels * S;
         h->host_hits += h->hit_pixels * S;
     }
-    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(h, hipEventRecord(sl.ev_done, sl.stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_done, 0));
+    sl.accumulated = accumulate;
     if (accumulate) {
+        HIPCHK(h, hipEventRecord(sl.ev_acc0, h->stream));
         if (simple || dense) {
             HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, first, S, h->scene.width, h->scene.height,
                                               h->scene.shard_index, h->scene.shard_count, h->stream));
@@ -850,15 +926,51 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
                                              h->d_mean, h->d_m2, first, S, h->scene.width, h->scene.height,
                                              h->scene.shard_index, h->scene.shard_count, h->stream));
         }
+        HIPCHK(h, hipEventRecord(sl.ev_acc1, h->stream));
     }
-    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    HIPCHK(h, hipEventSynchronize(h->ev[2]));
-    float ms01 = 0, ms12 = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms01, h->ev[0], h->ev[1]));
-    HIPCHK(h, hipEventElapsedTime(&ms12, h->ev[1], h->ev[2]));
-    h->render_ms += ms01;
-    h->accum_ms += ms12;
-    h->launches += 1;
+    sl.pending = true;
+    return CT_OK;
+}
+
+// Job list etc. for batches of S subframes; everything in flight is waited for when it has to change.
+static int prepare_batches(CtHandle h, uint32_t S)
+{
+    const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
+    if (simple) {
+        return CT_OK;
+    }
+    if (h->queue_dirty || h->jobs_S != S) {
+        int rc = flush(h);
+        if (rc == CT_OK && h->queue_dirty) {
+            rc = rebuild_queue(h);
+        }
+        if (rc == CT_OK) {
+            rc = build_jobs(h, S);
+        }
+        return rc;
+    }
+    return CT_OK;
+}
+
+// One launch of the estimator over S subframes into `frames` (+ optional accumulate), waited for.
+static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, bool accumulate)
+{
+    int rc = flush(h);
+    if (rc == CT_OK) {
+        rc = prepare_batches(h, S);
+    }
+    if (rc != CT_OK) {
+        return rc;
+    }
+    CtHandle_::Slot &sl = h->slots[0];
+    rc = submit_batch(h, sl, frames ? frames : sl.frames, first, S, accumulate);
+    if (rc == CT_OK) {
+        rc = collect(h, sl);
+    }
+    if (rc != CT_OK) {
+        return rc;
+    }
+    const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
     if (!simple && !h->order_tuned) {
         return tune_order(h, S);
     }
@@ -905,9 +1017,8 @@ extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *fram
     return CT_OK;
 }
 
-extern "C" int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint32_t count)
+static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32_t count, bool wait)
 {
-    NEED(h);
     if (!h->camera_set) {
         return fail(h, CT_E_STATE, "ct_set_camera has not been called");
     }
@@ -916,10 +1027,14 @@ extern "C" int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint
                     h->subframes);
     }
     if (count == 0) {
-        return CT_OK;
+        return wait ? flush(h) : CT_OK;
     }
-    if (h->queue_dirty && !(h->scene.flags & CT_FLAG_SIMPLE_KERNEL)) {
-        const int rc = rebuild_queue(h);
+    const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
+    if (h->queue_dirty && !simple) {
+        int rc = flush(h);
+        if (rc == CT_OK) {
+            rc = rebuild_queue(h);
+        }
         if (rc != CT_OK) {
             return rc;
         }
@@ -932,17 +1047,57 @@ extern "C" int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint
     uint32_t done = 0;
     while (done < count) {
         const uint32_t S = (uint32_t)std::min<uint64_t>(cap, count - done);
-        int rc = ensure_frames(h, S);
-        if (rc != CT_OK) {
-            return rc;
+        int rc;
+        if (!simple && !h->order_tuned) {
+            // the first launch of a pose measures the job costs: it is waited for, then the order is set
+            rc = ensure_frames(h, h->slots[0], S);
+            if (rc == CT_OK) {
+                rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
+            }
+        } else {
+            rc = prepare_batches(h, S);
+            CtHandle_::Slot &sl = h->slots[h->next_slot];
+            if (rc == CT_OK) {
+                rc = collect(h, sl); // at most two batches in flight: wait for the one that used this slot
+            }
+            if (rc == CT_OK) {
+                rc = ensure_frames(h, sl, S);
+            }
+            if (rc == CT_OK) {
+                rc = submit_batch(h, sl, sl.frames, first_subframe_id + done, S, true);
+            }
+            h->next_slot ^= 1;
         }
-        rc = run_batch(h, h->d_frames, first_subframe_id + done, S, true);
         if (rc != CT_OK) {
+            flush(h);
             return rc;
         }
         done += S;
         h->subframes += S;
     }
+    return wait ? flush(h) : CT_OK;
+}
+
+extern "C" int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint32_t count)
+{
+    NEED(h);
+    return render_accumulate_impl(h, first_subframe_id, count, true);
+}
+
+extern "C" int ct_render_accumulate_async(CtHandle h, uint32_t first_subframe_id, uint32_t count)
+{
+    NEED_NOFLUSH(h);
+    return render_accumulate_impl(h, first_subframe_id, count, false);
+}
+
+extern "C" int ct_synchronize(CtHandle h)
+{
+    NEED(h);
+    const int rc = flush(h);
+    if (rc != CT_OK) {
+        return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return CT_OK;
 }
 
@@ -1266,6 +1421,22 @@ extern "C" int ct_copy_to_device(CtHandle h, int32_t which, void *dst_dev, size_
     return CT_OK;
 }
 
+extern "C" int ct_copy_to_device_async(CtHandle h, int32_t which, void *dst_dev, size_t dst_bytes)
+{
+    NEED_NOFLUSH(h);
+    void *p;
+    size_t b = 0;
+    const int rc = buffer_info(h, which, &p, &b);
+    if (rc != CT_OK) {
+        return rc;
+    }
+    if (!dst_dev || dst_bytes != b) {
+        return fail(h, CT_E_INVAL, "ct_copy_to_device_async: need %zu bytes, got %zu", b, dst_bytes);
+    }
+    HIPCHK(h, hipMemcpyAsync(dst_dev, p, b, hipMemcpyDeviceToDevice, h->stream));
+    return CT_OK;
+}
+
 extern "C" int ct_device_ptr(CtHandle h, int32_t which, void **ptr_out)
 {
     NEED(h);
@@ -1278,7 +1449,7 @@ extern "C" int ct_device_ptr(CtHandle h, int32_t which, void **ptr_out)
 
 extern "C" int ct_subframes(CtHandle h, uint32_t *count_out)
 {
-    NEED(h);
+    NEED_NOFLUSH(h); // host-side count of the subframes submitted so far
     if (count_out) {
         *count_out = h->subframes;
     }

@@ -47,6 +47,7 @@ class ShardedTracer:
         self.tracer = CloudTracer(density, params)
         self.merged = torch.zeros((params.height, params.width, 4), dtype=torch.float32, device="cuda")
         self._nbytes = self.merged.numel() * 4
+        self._shares_stream = False
 
     def step(self, first_subframe: int, count: int):
         """Render + accumulate `count` subframes of this shard, then reduce the frame to rank 0.
@@ -57,6 +58,29 @@ class ShardedTracer:
             frame_reduce(self.merged, 0)
             return self.merged
         return None
+
+    def step_async(self, first_subframe: int, count: int):
+        """The same without waiting: the batch is enqueued (two may be in flight, see
+        ct_render_accumulate_async); the copy of the running mean and the RCCL reduce are ordered behind
+        its accumulate kernel on torch's current stream, which the handle shares.  `merged` is valid on
+        rank 0 after `synchronize()`."""
+        if self.world > 1 and not self._shares_stream:
+            torch = self.torch
+            if torch.distributed.get_backend() != "nccl":
+                return self.step(first_subframe, count)     # host-staged rehearsal backends cannot be ordered on a stream
+            self.tracer.set_stream(torch.cuda.current_stream().cuda_stream)
+            self._shares_stream = True
+        self.tracer.render_accumulate_async(first_subframe, count)
+        if self.world > 1:
+            self.tracer.copy_to_device_async(_lib.CT_BUF_MEAN, self.merged.data_ptr(), self._nbytes)
+            frame_reduce(self.merged, 0)
+            return self.merged
+        return None
+
+    def synchronize(self):
+        self.tracer.synchronize()
+        if self.world > 1:
+            self.torch.cuda.synchronize()
 
     def close(self):
         self.tracer.close()

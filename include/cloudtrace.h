@@ -183,6 +183,17 @@ CT_API int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *frame_rg
  * without materialising the frame buffer.  Requires first == (subframes accumulated so far)+1. */
 CT_API int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint32_t count);
 
+/* The same, pipelined: the call enqueues the batch and returns.  Up to two batches are in flight: the
+ * estimator launch of batch k+1 runs on a second HIP stream while the last long paths of batch k finish
+ * (a launch cannot be shorter than its deepest path), the accumulate kernels stay in subframe order on
+ * the handle's stream (ct_set_stream), so results are identical to ct_render_accumulate's.  A third call
+ * waits for the oldest batch.  Every other entry point waits for the batches in flight first, except
+ * ct_copy_to_device_async, which is ordered on the handle's stream behind the accumulate kernels.
+ * (The reference is synchronous: Camera::render maps its buffers right after context->launch,
+ * Camera.cpp:189-240; SURVEY section 8b asks for an _async variant.) */
+CT_API int ct_render_accumulate_async(CtHandle h, uint32_t first_subframe_id, uint32_t count);
+CT_API int ct_synchronize(CtHandle h);
+
 /* Camera::reset, Camera.cpp:77-86 (clearScreen, progressive.cu:29-34): zero frame, mean, M2,
  * subframe count.  Counters are zeroed too. */
 CT_API int ct_reset(CtHandle h);
@@ -260,6 +271,8 @@ CT_API int ct_device_ptr(CtHandle h, int32_t which /*CtBuffer*/, void **ptr_out)
 /* Device-to-device copy of a whole buffer into caller-owned device memory (e.g. a tensor that a
  * collective will reduce), on the handle's stream; returns after the copy completed. */
 CT_API int ct_copy_to_device(CtHandle h, int32_t which /*CtBuffer*/, void *dst_dev, size_t dst_bytes);
+/* Enqueued on the handle's stream, not waited for (see ct_render_accumulate_async). */
+CT_API int ct_copy_to_device_async(CtHandle h, int32_t which, void *dst_dev, size_t dst_bytes);
 
 /* Number of subframes accumulated (Camera::subframeId, Camera.h:76). */
 CT_API int ct_subframes(CtHandle h, uint32_t *count_out);

@@ -409,6 +409,50 @@ def test_delta_agrees_with_march_statistically():
     assert np.all(np.abs(b1 - b0) <= 4 * se + 0.02 * np.maximum(b0, 1e-3)), (np.abs(b1 - b0) / (se + 1e-12)).max()
 
 
+def test_pipelined_batches_equal_synchronous_batches():
+    """ct_render_accumulate_async: two batches in flight on two streams, accumulate in subframe order --
+    mean, M2 and counters must equal the synchronous calls' and the oracle's, whatever is interleaved."""
+    tex = sphere_volume(40, seed=13)
+    w, h = 56, 40
+    tr, orc = make_pair(tex, w, h, mode=0)
+    ref = ds.CloudTracer(tex, width=w, height=h, mode=0)
+    sizes = [3, 2, 4, 1, 5, 2]
+    first = 1
+    for n in sizes:
+        tr.render_accumulate_async(first, n)
+        ref.render_accumulate(first, n)
+        first += n
+    assert tr.subframes == sum(sizes)
+    tr.synchronize()
+    mean, m2 = orc.render(sum(sizes))
+    assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2)
+    assert np.array_equal(ref.mean(), mean) and np.array_equal(ref.m2(), m2)
+    assert tr.counters() == ref.counters() == orc.counters.as_dict()
+    # entry points that read results wait for the batches in flight by themselves
+    tr.render_accumulate_async(first, 3)
+    tr.render_accumulate_async(first + 3, 3)
+    got = tr.mean()                                   # no explicit synchronize
+    ref.render_accumulate(first, 6)
+    assert np.array_equal(got, ref.mean())
+    # a new pose while batches are in flight
+    eye = (0.3, 2.2, 0.4)
+    U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
+    tr.render_accumulate_async(first + 6, 2)
+    tr.set_camera(eye, U, V, W)
+    ref.render_accumulate(first + 6, 2)
+    ref.set_camera(eye, U, V, W)
+    tr.reset()
+    ref.reset()
+    tr.render_accumulate_async(1, 4)
+    tr.render_accumulate_async(5, 4)
+    ref.render_accumulate(1, 8)
+    assert np.array_equal(tr.mean(), ref.mean()) and np.array_equal(tr.m2(), ref.m2())
+    render_ms, accum_ms, launches = tr.kernel_time()
+    assert launches == 2 and render_ms > 0 and accum_ms > 0
+    tr.close()
+    ref.close()
+
+
 def test_descriptors_bit_exact_vs_oracle():
     """ct_collect_descriptors (setupHierarchicalDescriptor, DisneyDescriptor.cuh:71-112): the mip pyramid,
     the mip-linear trilinear sampler, the light/view frame and the fade outside the box, byte for byte."""

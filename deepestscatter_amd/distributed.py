@@ -37,50 +37,64 @@ def frame_reduce(local, dst: int = 0):
 
 
 class ShardedTracer:
-    """A CloudTracer for this rank's shard plus the per-step frame reduce."""
+    """A CloudTracer for this rank's shard plus the per-step frame reduce.
 
-    def __init__(self, density: np.ndarray, params: SceneParams, rank: int, world: int, local_rank: int = 0):
+    The handle's stream is a torch stream of this object, so what the library enqueues (accumulate
+    kernels, the copy of the running mean into `merged`) and what torch enqueues (the RCCL reduce of
+    `merged`) are ordered by plain stream order, with or without waiting in between."""
+
+    def __init__(self, density: np.ndarray, params: SceneParams, rank: int, world: int, local_rank: int = 0,
+                 stage_always: bool = False):
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
         params.shard_index, params.shard_count, params.device = rank, world, local_rank
         self.tracer = CloudTracer(density, params)
+        self.stage = world > 1 or stage_always       # stage_always: single-rank rehearsal of the staged path
         self.merged = torch.zeros((params.height, params.width, 4), dtype=torch.float32, device="cuda")
         self._nbytes = self.merged.numel() * 4
-        self._shares_stream = False
+        self.stream = None
+        if self.stage:
+            torch.cuda.synchronize()                 # `merged` is zeroed before another stream touches it
+            self.stream = torch.cuda.Stream()
+            self.tracer.set_stream(self.stream.cuda_stream)
+
+    def _reduce(self):
+        import torch.distributed as dist
+        on_stream = not (dist.is_available() and dist.is_initialized()) or dist.get_backend() == "nccl"
+        if on_stream:
+            with self.torch.cuda.stream(self.stream):
+                frame_reduce(self.merged, 0)
+        else:
+            # rehearsal backends stage through the host: wait for the copy first
+            self.stream.synchronize()
+            frame_reduce(self.merged, 0)
 
     def step(self, first_subframe: int, count: int):
         """Render + accumulate `count` subframes of this shard, then reduce the frame to rank 0.
         Returns the merged running mean (valid on rank 0)."""
         self.tracer.render_accumulate(first_subframe, count)
-        if self.world > 1:
+        if self.stage:
             self.tracer.copy_to_device(_lib.CT_BUF_MEAN, self.merged.data_ptr(), self._nbytes)
-            frame_reduce(self.merged, 0)
+            self._reduce()
             return self.merged
         return None
 
     def step_async(self, first_subframe: int, count: int):
         """The same without waiting: the batch is enqueued (two may be in flight, see
         ct_render_accumulate_async); the copy of the running mean and the RCCL reduce are ordered behind
-        its accumulate kernel on torch's current stream, which the handle shares.  `merged` is valid on
-        rank 0 after `synchronize()`."""
-        if self.world > 1 and not self._shares_stream:
-            torch = self.torch
-            if torch.distributed.get_backend() != "nccl":
-                return self.step(first_subframe, count)     # host-staged rehearsal backends cannot be ordered on a stream
-            self.tracer.set_stream(torch.cuda.current_stream().cuda_stream)
-            self._shares_stream = True
+        its accumulate kernel on the shared stream.  `merged` is valid on rank 0 after `synchronize()`."""
         self.tracer.render_accumulate_async(first_subframe, count)
-        if self.world > 1:
+        if self.stage:
             self.tracer.copy_to_device_async(_lib.CT_BUF_MEAN, self.merged.data_ptr(), self._nbytes)
-            frame_reduce(self.merged, 0)
+            self._reduce()
             return self.merged
         return None
 
     def synchronize(self):
         self.tracer.synchronize()
-        if self.world > 1:
-            self.torch.cuda.synchronize()
+        if self.stream is not None:
+            self.stream.synchronize()
 
     def close(self):
         self.tracer.close()

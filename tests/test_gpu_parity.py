@@ -453,6 +453,31 @@ def test_pipelined_batches_equal_synchronous_batches():
     ref.close()
 
 
+def test_sharded_tracer_staged_async_path_single_rank():
+    """The multi-GPU step without a second GPU: the handle shares a torch stream, every step enqueues
+    render + accumulate + the copy of the running mean into the staging tensor (the RCCL reduce is a
+    no-op for one rank).  The staging tensor must hold the running mean after synchronize()."""
+    torch = pytest.importorskip("torch")
+    from deepestscatter_amd.distributed import ShardedTracer
+    tex = sphere_volume(32, seed=8)
+    w, h = 40, 24
+    st = ShardedTracer(tex, ds.SceneParams(width=w, height=h, mode=0), 0, 1, 0, stage_always=True)
+    ref = ds.CloudTracer(tex, width=w, height=h, mode=0)
+    first = 1
+    for n in (2, 3, 2, 4):
+        st.step_async(first, n)
+        ref.render_accumulate(first, n)
+        first += n
+    st.synchronize()
+    assert np.array_equal(st.merged.cpu().numpy(), ref.mean())
+    st.step(first, 2)
+    ref.render_accumulate(first, 2)
+    st.synchronize()
+    assert np.array_equal(st.merged.cpu().numpy(), ref.mean())
+    st.close()
+    ref.close()
+
+
 def test_descriptors_bit_exact_vs_oracle():
     """ct_collect_descriptors (setupHierarchicalDescriptor, DisneyDescriptor.cuh:71-112): the mip pyramid,
     the mip-linear trilinear sampler, the light/view frame and the fade outside the box, byte for byte."""

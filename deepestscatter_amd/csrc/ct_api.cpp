@@ -841,7 +841,9 @@ static int collect(CtHandle h, CtHandle_::Slot &sl)
     HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_start, sl.ev_done));
     h->render_ms += ms;
     if (sl.accumulated) {
-        HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_acc0, sl.ev_acc1));
+        // from the end of the estimator launch (the accumulate kernel waits for exactly that) to the end
+        // of the accumulate kernel; an event recorded on the main stream behind the wait is stamped too early
+        HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_done, sl.ev_acc1));
         h->accum_ms += ms;
     }
     h->launches += 1;

@@ -522,8 +522,11 @@ CT_DEV NeeLoads in_scattering_issue(const DevScene &sc, f3 pos, f3 dir, bool cho
     const float *table = chopped ? sc.chopped : sc.mie;
     const float x = fmaf(u, (float)kMieN, -0.5f);
     const int32_t i = (int32_t)floorf(x);
-    n.a = table[min(max(i, 0), kMieN - 1)];
-    n.b = table[min(max(i + 1, 0), kMieN - 1)];
+    // entries clamp(i) and clamp(i+1) with one 8-byte gather: they are neighbours unless i is -1 or 4095
+    float2 pair;
+    __builtin_memcpy(&pair, table + min(max(i, 0), kMieN - 2), sizeof pair);
+    n.a = (i > kMieN - 2) ? pair.y : pair.x;
+    n.b = (i < 0) ? pair.x : pair.y;
     n.w = fract_(x);
     uint32_t meta_unused;
     n.cell = fetch_cell(sc, sc.ibricks, pos, meta_unused);

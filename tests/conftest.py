@@ -5,6 +5,15 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+# torch first: its wheel bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever copy a
+# process loads first serves both torch and libcloudtrace.so; torch on top of the system copy fails
+# to find a GPU ("No HIP GPUs are available"), libcloudtrace.so works on either (bench.py loads torch
+# first too).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is plumbing, the CPU tests do not need it
+    torch = None
+
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))

@@ -2,6 +2,7 @@
 // PathTracingRenderer.{h,cpp},Camera.{h,cpp}} on top of the libcloudtrace C ABI.
 #pragma once
 
+#include "Exr.h"
 #include <algorithm>
 #include <cfloat>
 #include <filesystem>
@@ -123,16 +124,23 @@ namespace DeepestScatter
         uint32_t getSubframeId() const { return subframeId; }
         const std::vector<uint8_t>& getScreen() const { return screen; }
 
-        void saveToDisk() const                                                  // :149-175 (EXR R,G,B FLOAT there)
+        void saveToDisk() const                                                  // :149-175
         {
-            // OpenEXR is not available on the target image: write a PFM (RGB float32, bottom row first,
-            // which is exactly the buffer's own row order: row 0 = bottom).
             std::vector<float> mean((size_t)width * height * 4);
             Context::check(ct_download(context->handle, CT_BUF_MEAN, mean.data(), mean.size() * sizeof(float)), context->handle, "ct_download");
             std::cout << mean[((size_t)width * height / 2 + width / 2) * 4] << std::endl;   // :163
-            std::ofstream f(outputFile, std::ios::binary);
-            f << "PF\n" << width << " " << height << "\n-1.0\n";
-            for (size_t i = 0; i < (size_t)width * height; i++) f.write(reinterpret_cast<const char*>(&mean[4 * i]), 3 * sizeof(float));
+            if (outputFile.extension() == ".pfm")
+            {
+                // RGB float32, bottom row first, which is the buffer's own row order (row 0 = bottom)
+                std::ofstream f(outputFile, std::ios::binary);
+                f << "PF\n" << width << " " << height << "\n-1.0\n";
+                for (size_t i = 0; i < (size_t)width * height; i++) f.write(reinterpret_cast<const char*>(&mean[4 * i]), 3 * sizeof(float));
+            }
+            else
+            {
+                // EXR, channels R, G, B FLOAT, DECREASING_Y, pixel (x, y) = progressive[y * width + x] like the reference
+                Exr::writeRgbFloat(outputFile.string(), width, height, mean.data());
+            }
         }
 
     private:

@@ -1,10 +1,10 @@
 // cloudtrace -- headless equivalent of the reference's entry point for the path-traced image:
 // main (src/main.cpp:26-77) -> Tasks::renderCloud (ExecutionLoop/Tasks.cpp:49-112): two tasks, light
-// "Side" then "Back", 512x256, 7000 m, output <cloud>.<Light>.PT.pfm.  The GLUT loop
+// "Side" then "Back", 512x256, 7000 m, output <cloud>.<Light>.PT.exr (Tasks.cpp:88-90; --format pfm for PFM).  The GLUT loop
 // (GuiExecutionLoop.cpp:85-128) becomes a plain while(!scene->isCompleted()) scene->update().
 //
 //   cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light Side|Back|Front]
-//              [--size-m 7000] [--out DIR] [--data DIR] [--unfused]
+//              [--size-m 7000] [--out DIR] [--data DIR] [--unfused] [--format exr|pfm]
 //   <cloud> = procedural:<N>[:<seed>] | file.f32grid
 #include <chrono>
 #include <cstring>
@@ -43,7 +43,7 @@ namespace
         Cloud::Rendering::Mode mode = Cloud::Rendering::Mode::SunAndSkyAllScatter;
         std::vector<LightDirection> lights = { LightDirection::Side, LightDirection::Back };   // Tasks.cpp:108-109
         float sizeM = 7000.f;                                                     // main.cpp:63
-        std::string outDir = ".", dataDir;
+        std::string outDir = ".", dataDir, format = "exr";
         bool fused = true;
     };
 
@@ -63,7 +63,7 @@ namespace
                 DirectionalLight{ direction, Color{ 1, 1, 1 }, 1e6f } };
             std::string stem = std::filesystem::path(opt.cloud).filename().string();
             std::replace(stem.begin(), stem.end(), ':', '_');
-            auto outputPath = std::filesystem::path(opt.outDir) / (stem + "." + toString(lightDirection) + "." + PathTracingRenderer::NAME + ".pfm");
+            auto outputPath = std::filesystem::path(opt.outDir) / (stem + "." + toString(lightDirection) + "." + PathTracingRenderer::NAME + "." + opt.format);
             // installFramework + installApp: Sun, VDBCloud, CloudMaterial, Camera in this order (installers.cpp:28-38)
             auto renderer = std::make_shared<PathTracingRenderer>(context);
             auto sun = std::make_shared<Sun>(std::make_shared<DirectionalLight>(scene.light), context);
@@ -84,7 +84,7 @@ int main(int argc, char* argv[])
     try
     {
         Options opt;
-        if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused]\n"; return 2; }
+        if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused] [--format exr|pfm]\n"; return 2; }
         opt.cloud = argv[1];
         opt.dataDir = (std::filesystem::path(argv[0]).parent_path() / ".." / "data").string();
         for (int i = 2; i < argc; i++)
@@ -97,6 +97,7 @@ int main(int argc, char* argv[])
             else if (a == "--out") opt.outDir = next();
             else if (a == "--data") opt.dataDir = next();
             else if (a == "--unfused") opt.fused = false;
+            else if (a == "--format") { opt.format = next(); if (opt.format != "exr" && opt.format != "pfm") throw std::invalid_argument("--format exr|pfm"); }
             else if (a == "--mode")
             {
                 const std::string m = next();

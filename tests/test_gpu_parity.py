@@ -299,30 +299,38 @@ def test_error_behaviour_on_device():
 
 def test_cpp_host_cli_matches_python_path(tmp_path):
     """The C++ mirror of the reference's Scene/Camera/PathTracingRenderer classes (headless
-    `cloudtrace`, = main.cpp + Tasks::renderCloud) drives the same C ABI: its PFM output equals the
+    `cloudtrace`, = main.cpp + Tasks::renderCloud) drives the same C ABI: its EXR (and PFM) output equals the
     running mean obtained through the Python binding, for the fused and the two-launch loop."""
     import subprocess
     from deepestscatter_amd import build
     cli = build.build_cli()
     tex = ds.make_procedural_cloud(32)
-    for extra in ([], ["--unfused"]):
+    from deepestscatter_amd import exr
+    tr = ds.CloudTracer(tex, width=40, height=24, light_direction=ds.LIGHT_DIRECTIONS["Back"])
+    tr.render_accumulate(1, 5)
+    want = tr.mean()[..., :3]
+    tr.close()
+    for extra in ([], ["--unfused", "--format", "pfm"]):
         out = tmp_path / ("u" if extra else "f")
         out.mkdir()
         r = subprocess.run([str(cli), "procedural:32", "--size", "40x24", "--spp", "5", "--light", "Back",
                             "--out", str(out), *extra], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "rendering subframe 5" in r.stdout and "MS/FRAME" in r.stdout
-        pfm = out / "procedural_32.Back.PT.pfm"
-        raw = pfm.read_bytes()
-        header_end = 0
-        for _ in range(3):
-            header_end = raw.index(b"\n", header_end) + 1
-        assert raw[:header_end].split() == [b"PF", b"40", b"24", b"-1.0"]
-        img = np.frombuffer(raw[header_end:], "<f4").reshape(24, 40, 3)
-        tr = ds.CloudTracer(tex, width=40, height=24, light_direction=ds.LIGHT_DIRECTIONS["Back"])
-        tr.render_accumulate(1, 5)
-        assert np.array_equal(img, tr.mean()[..., :3])
-        tr.close()
+        if extra:
+            raw = (out / "procedural_32.Back.PT.pfm").read_bytes()
+            header_end = 0
+            for _ in range(3):
+                header_end = raw.index(b"\n", header_end) + 1
+            assert raw[:header_end].split() == [b"PF", b"40", b"24", b"-1.0"]
+            img = np.frombuffer(raw[header_end:], "<f4").reshape(24, 40, 3)
+        else:
+            # the reference's output: <cloud>.<Light>.PT.exr, R/G/B FLOAT, DECREASING_Y (Camera.cpp:149-175)
+            path = out / "procedural_32.Back.PT.exr"
+            img = exr.read_exr(path)
+            raw = path.read_bytes()
+            assert raw[:8] == b"\x76\x2f\x31\x01\x02\x00\x00\x00" and b"lineOrder\0lineOrder\0\x01\0\0\0\x01" in raw
+        assert np.array_equal(img, want)
     bad = subprocess.run([str(cli), "procedural:32", "--mode", "bogus"], capture_output=True, text=True)
     assert bad.returncode == 1 and "Invalid Render Mode" in bad.stdout      # CloudMaterial.cpp:62 / main.cpp:65-76
 

@@ -332,3 +332,22 @@ def test_descriptor_known_answers():
     # layer 1: one texel per grid step at LOD 0; z index 8 = +6*eZ = 6 texels towards -z, index 0 = 2 towards +z
     assert d3[1, 8].min() >= 254 and d3[1, 0].max() == 0
     assert not o.collect_descriptors([[0, 0, 0]], [[1, 0, 0]]).any()
+
+
+def test_exr_writer_reader_round_trip(tmp_path):
+    """deepestscatter_amd.exr: the single-part, uncompressed, FLOAT B/G/R scan-line layout of Camera::saveToDisk."""
+    from deepestscatter_amd import exr
+    rng = np.random.default_rng(5)
+    img = rng.normal(size=(9, 13, 3)).astype(np.float32)
+    for dec in (True, False):
+        p = tmp_path / f"a{int(dec)}.exr"
+        exr.write_exr(p, img, decreasing_y=dec)
+        raw = p.read_bytes()
+        assert raw[:8] == b"\x76\x2f\x31\x01\x02\x00\x00\x00"
+        for name in (b"channels\0chlist\0", b"compression\0compression\0", b"dataWindow\0box2i\0", b"displayWindow\0box2i\0",
+                     b"lineOrder\0lineOrder\0", b"pixelAspectRatio\0float\0", b"screenWindowCenter\0v2f\0",
+                     b"screenWindowWidth\0float\0"):
+            assert name in raw                      # the eight attributes every OpenEXR header must have
+        assert np.array_equal(exr.read_exr(p), img)
+    # size = header + offset table + height * (8 + 3 * width * 4)
+    assert len(raw) - raw.index(b"screenWindowWidth") < 40 + 8 * 9 + 9 * (8 + 3 * 13 * 4)

@@ -7,11 +7,13 @@ reduce of the accumulated radiance buffer).
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one progressive batch of --spp-per-step (default 128 x n_gpus) subframes of the whole
+A "step" = one progressive batch of --spp-per-step (default 256 x n_gpus) subframes of the whole
 frame: estimator kernel + Welford accumulate kernel, plus (N>1) the reduce of the W*H float4
-radiance buffer to rank 0.  (The reference updates its display every 10 subframes and saves every
-40, Camera.cpp:189,211; a launch cannot be shorter than its deepest 2000-bounce path, ~11 ms, so
-batches of 128 subframes per GPU keep that tail near 10 % of a step: 8 updates per 1024-spp image.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
+radiance buffer to rank 0.  The default run (4 steps) is exactly one 1024-spp image of
+BASELINE.json's configuration in four progressive updates.  (The reference updates its display
+every 10 subframes and saves every 40, Camera.cpp:189,211; a launch ends with a tail of waves that
+finish its long paths, 14.6 ms + 0.44 ms per spp measured, so the batch size trades update rate for
+throughput: 1510 Msamples/s at 64 spp per launch, 1880 at 128, 2030 at 256, 2080 at 512.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
 before the timed region and resident in HBM).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -41,7 +43,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp-per-step", type=int, default=0,
                     help="subframes per progressive batch (one estimator launch + one accumulate launch); "
-                         "default 128 x n_gpus, i.e. a constant number of samples per GPU per launch")
+                         "default 256 x n_gpus, i.e. a constant number of samples per GPU per launch")
     ap.add_argument("--mode", type=int, default=0, help="0 totalRadiance (Mie multi-scatter + NEE)")
     ap.add_argument("--estimator", type=int, default=0, choices=(0, 1),
                     help="0 MARCH = the reference's free-flight sampler (the parity path, default); "
@@ -52,9 +54,8 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a box with one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
-    ap.add_argument("--sync-steps", action="store_true",
-                    help="wait for every step before enqueuing the next (no overlap of a launch's tail with the "
-                         "next launch)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="enqueue the steps (two launches in flight) instead of waiting for each one")
     return ap.parse_args()
 
 
@@ -118,7 +119,7 @@ def main():
             dist.init_process_group(args.backend)
 
     W, H = args.width, args.height
-    S = args.spp_per_step if args.spp_per_step > 0 else 128 * world
+    S = args.spp_per_step if args.spp_per_step > 0 else 256 * world
     t_setup = time.perf_counter()
     tex = ds.make_procedural_cloud(args.volume)
     flags = _lib.CT_FLAG_SIMPLE_KERNEL if args.simple_kernel else 0
@@ -129,13 +130,15 @@ def main():
 
     def step(first):
         # estimator + accumulate on this rank's tiles, then (N>1) the RCCL SUM-reduce of the W*H float4
-        # radiance buffer to rank 0: tiles are disjoint, so the sum is an exact merge.  Steps are enqueued
-        # (--sync-steps: waited for one by one): the estimator launch of step k+1 starts on a second HIP
-        # stream while the last long paths of step k finish; accumulate, copy and reduce stay in order.
-        if args.sync_steps:
-            st.step(first, S)
-        else:
+        # radiance buffer to rank 0: tiles are disjoint, so the sum is an exact merge.  --pipelined enqueues
+        # the steps instead (ct_render_accumulate_async: the estimator launch of step k+1 starts on a
+        # second HIP stream while the last long paths of step k finish; accumulate, copy and reduce stay in
+        # order): +4 % at 128 spp per step, -3 % at 256, where two co-running launches disturb each other
+        # for longer than the tail they hide.
+        if args.pipelined:
             st.step_async(first, S)
+        else:
+            st.step(first, S)
 
     def fence():
         st.synchronize()
@@ -217,7 +220,7 @@ def main():
                         f"{('MARCH (reference-faithful)', 'DELTA (Woodcock, brick majorants)')[args.estimator]}, max_depth 2000",
             "volume": args.volume, "width": W, "height": H, "spp_per_step": S,
             "parallelism": f"pixel-tile shard x{world}" + (" + RCCL reduce of the radiance buffer" if world > 1 else ""),
-            "pipelined_steps": not args.sync_steps,
+            "pipelined_steps": bool(args.pipelined),
         },
         "roofline": roofline,
         "setup_s": setup_s,

@@ -1203,12 +1203,10 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
         const uint64_t bouncing = __builtin_amdgcn_ballot_w64(state == ST_BOUNCE);
         const uint32_t nm = (uint32_t)__builtin_popcountll(marching);
         const uint32_t nb = (uint32_t)__builtin_popcountll(bouncing);
-        if ((marching | bouncing) == 0) {
-            if (drained && q_next == q_end) {
-                break;
-            }
-            continue;
+        if ((marching | bouncing) == 0 && drained && q_next == q_end) {
+            break;
         }
+        // (everything idle but samples left: both phases below are no-ops and the loop regenerates)
 
         bool finished = false;
         if (nb != 0 && (nb >= sc.scatter_min || nm == 0)) {
@@ -1239,14 +1237,17 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
                 }
             }
         } else {
-            // ---------------- one tracking visit ----------------
+            // ---------------- tracking visits: a burst, like the march bursts of render_persistent_kernel ----------------
             if (STATS) {
                 st_march += 1;
                 st_march_l += nm;
             }
+            uint32_t burst = drained ? sc.tail_burst : sc.march_burst;
+            for (;;) {
             if (state == ST_MARCH) {
+                bool ended = false;
                 if (!brick_in_grid(sc, dda)) {
-                    finished = true; // left the grid without a collision
+                    ended = true; // left the grid without a collision
                 } else {
                     const uint32_t M = dda.meta >> 8;
                     bool crossed = false;
@@ -1286,7 +1287,7 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
                                 if (in_box(sc, pos)) {
                                     state = ST_BOUNCE;
                                 } else {
-                                    finished = true;
+                                    ended = true;
                                 }
                             }
                         }
@@ -1295,6 +1296,27 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
                         dda.meta = brick_in_grid(sc, dda) ? load_brick_meta(sc, dda.bx, dda.by, dda.bz) : 0u;
                     }
                 }
+                if (ended) {
+                    ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                    if (ba.cost) {
+                        atomicAdd(&ba.cost[group], depth);
+                        atomicMax(&ba.cost_max[group], depth);
+                    }
+                    state = ST_IDLE;
+                }
+            }
+            if (--burst == 0u) {
+                break;
+            }
+            const uint32_t m_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_MARCH));
+            const uint32_t b_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_BOUNCE));
+            if (m_now == 0u || b_now >= sc.burst_scatter || 64u - m_now - b_now >= sc.burst_idle) {
+                break;
+            }
+            if (STATS) {
+                st_march += 1;
+                st_march_l += m_now;
+            }
             }
         }
         if (finished) {

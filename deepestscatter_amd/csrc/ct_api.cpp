@@ -1019,6 +1019,9 @@ extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *fram
     return CT_OK;
 }
 
+// Subframes of the launch that measures the job costs of a new pose.
+constexpr uint32_t kTuneSubframes = 32;
+
 static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32_t count, bool wait)
 {
     if (!h->camera_set) {
@@ -1048,10 +1051,12 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
     cap = std::max<uint64_t>(std::min<uint64_t>(cap, 0xffffull), 1);
     uint32_t done = 0;
     while (done < count) {
-        const uint32_t S = (uint32_t)std::min<uint64_t>(cap, count - done);
+        uint32_t S = (uint32_t)std::min<uint64_t>(cap, count - done);
         int rc;
         if (!simple && !h->order_tuned) {
-            // the first launch of a pose measures the job costs: it is waited for, then the order is set
+            // the first launch of a pose measures the job costs (two atomics per path, jobs in image
+            // order): it is kept short, waited for, then the order is set
+            S = std::min(S, kTuneSubframes);
             rc = ensure_frames(h, h->slots[0], S);
             if (rc == CT_OK) {
                 rc = run_batch(h, nullptr, first_subframe_id + done, S, true);

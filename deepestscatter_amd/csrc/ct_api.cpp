@@ -1056,8 +1056,8 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
         if (!simple && !h->order_tuned) {
             // the first launch of a pose measures the job costs (two atomics per path, jobs in image
             // order): it is kept short, waited for, then the order is set
+            rc = ensure_frames(h, h->slots[0], S); // sized for the batches that follow, not for this short one
             S = std::min(S, kTuneSubframes);
-            rc = ensure_frames(h, h->slots[0], S);
             if (rc == CT_OK) {
                 rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
             }

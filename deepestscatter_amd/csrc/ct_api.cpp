@@ -55,6 +55,7 @@ struct CtHandle_ {
     int next_slot = 0;
     // work queue of the persistent kernel (rebuilt when the camera moves)
     float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
+    float4 *d_advance = nullptr;      // per pixel: pre-walked prefix of the primary march (MARCH estimator)
     uint32_t *d_pixels = nullptr;     // this shard's box-hitting pixels, padded to groups of 64
     uint32_t *d_cost = nullptr;       // measured per group: [0,n) sum of path costs, [n,2n) deepest path
     uint32_t *d_job_group = nullptr, *d_job_sub = nullptr; // job list of the current batch size
@@ -63,6 +64,7 @@ struct CtHandle_ {
     uint32_t q_begin[kQueues + 2] = {}; // job ranges of the per-XCD queues + the shared one
     uint64_t own_pixels = 0, hit_pixels = 0;
     bool queue_dirty = true, order_tuned = false;
+    bool no_advance = false;             // CT_NO_ADVANCE=1: samples start at the box face (A/B)
     bool queues_enabled = false;         // per-XCD regions (CT_XCD_QUEUES=1; default: one global list)
     float shared_depth = 1e30f;          // groups at least this deep (bounces) use the shared queue
     uint32_t regions = 128;              // image regions dealt to the per-XCD queues
@@ -223,7 +225,7 @@ static void release(CtHandle h)
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->slots[0].frames, h->slots[1].frames, h->slots[0].queue, h->slots[1].queue, h->d_primary, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->slots[0].frames, h->slots[1].frames, h->slots[0].queue, h->slots[1].queue, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
         if (p) {
@@ -332,6 +334,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     // the speed (the kernel is bound by the L1 gather rate and by instruction issue, not by L2
     // misses), and any imbalance between regions costs more than that: off unless asked for
     h->queues_enabled = false;
+    if (const char *e = getenv("CT_NO_ADVANCE")) {
+        h->no_advance = atoi(e) != 0;
+    }
     if (const char *e = getenv("CT_XCD_QUEUES")) {
         h->queues_enabled = atoi(e) != 0;
     }
@@ -487,6 +492,7 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1 + kStatCount) * sizeof(unsigned long long), h->stream));
 
     HIPCHK(h, dmalloc(&h->d_primary, 2 * pixels));
+    HIPCHK(h, dmalloc(&h->d_advance, pixels));
     HIPCHK(h, hipStreamSynchronize(h->stream));
 
     // ---- default pose: Camera.cpp:37-39 through sutil::calculateCameraVariables
@@ -604,6 +610,7 @@ static int rebuild_queue(CtHandle h)
     const uint32_t W = h->scene.width, H = h->scene.height;
     const size_t pixels = (size_t)W * H;
     HIPCHK(h, launch_primary_rays(h->dev, h->d_primary, h->stream));
+    HIPCHK(h, launch_primary_advance(h->dev, h->d_primary, h->d_advance, h->stream));
     std::vector<float4> prim(2 * pixels);
     HIPCHK(h, hipMemcpyAsync(prim.data(), h->d_primary, prim.size() * sizeof(float4), hipMemcpyDeviceToHost,
                              h->stream));
@@ -873,6 +880,7 @@ static int submit_batch(CtHandle h, CtHandle_::Slot &sl, float4 *frames, uint32_
     ba.frames = frames;
     ba.frame_stride = (simple || dense) ? 0u : h->n_groups * 64u;
     ba.primary = h->d_primary;
+    ba.advance = (h->scene.estimator == CT_EST_MARCH && !h->no_advance) ? h->d_advance : nullptr;
     ba.pixels = h->d_pixels;
     ba.job_group = h->d_job_group;
     ba.job_sub = h->d_job_sub;

@@ -553,6 +553,29 @@ CT_DEV float inv_max_advance(const DevScene &sc, f3 stepv)
 }
 
 
+// Free-space skip of the march (see render_persistent_kernel): how many steps the clearance `c`
+// (texels) of the row the last fetch was based in allows, and their replay.  The adds are the work;
+// a wave-level branch per add is not: blocks of 8, then singles (measured: 1815 -> 1891 Msamples/s;
+// 16/4/1 is no better).
+CT_DEV int skip_steps(uint32_t c, float inv_maxd)
+{
+    return (int)(((float)c - 0.03125f) * inv_maxd);
+}
+
+CT_DEV void replay_steps(f3 &pos, f3 stepv, int n)
+{
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            pos = add3(pos, stepv);
+        }
+    }
+    for (; i < n; i++) {
+        pos = add3(pos, stepv);
+    }
+}
+
 // The XCD this wave runs on (XCC_ID, hardware register 20, bits 3:0).
 CT_DEV uint32_t xcd_id()
 {
@@ -589,6 +612,58 @@ CT_DEV bool take_job(const BatchArgs &ba, uint32_t lane, uint32_t &q_cur, uint32
 CT_DEV uint32_t lane_rank(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// No jitter also means that every sample of a pixel marches the same way until its primary ray
+// meets the first non-zero footprint: T stays 1 and xi < 1 cannot collide.  That prefix -- mostly the
+// long free-space hops from the box face to the cloud -- is walked once per pose here, with exactly
+// the march phase's operations, and a sample starts at the state recorded BEFORE the decisive
+// iteration (the one whose fetch is non-zero or leaves the box), which it then executes itself:
+// advance[p] = (position, bits: steps done so far | clearance << 24).
+__global__ __launch_bounds__(256) void primary_advance_kernel(DevScene sc, const float4 *__restrict__ primary,
+                                                              float4 *__restrict__ advance)
+{
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
+    const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= sc.width || y >= sc.height) {
+        return;
+    }
+    const size_t p = (size_t)y * sc.width + x;
+    const float4 p0 = primary[2 * p], p1 = primary[2 * p + 1];
+    f3 pos = mk3(p0.x, p0.y, p0.z);
+    const f3 dir = mk3(p1.x, p1.y, p1.z);
+    f3 start = pos;
+    uint32_t start_bits = 0;
+    if (p0.w != 0.f && in_box(sc, pos)) {
+        const f3 stepv = scale3(dir, sc.sample_step);
+        const float inv_maxd = inv_max_advance(sc, stepv);
+        uint32_t dfree = 0, steps = 0;
+        for (int it = 0; it < 65536 && steps < 0x00f00000u; it++) {
+            start = pos;
+            start_bits = steps | (dfree << 24);
+            if (dfree != 0u) {
+                const int n = skip_steps(dfree, inv_maxd);
+                replay_steps(pos, stepv, n);
+                steps += (uint32_t)n;
+            }
+            pos = add3(pos, stepv);
+            steps += 1u;
+            uint32_t meta;
+            const uint2 cell = fetch_cell_m(sc, pos, meta);
+            dfree = meta & 0x7fu;
+            if ((cell.x | cell.y) != 0u || ((meta & 0x80u) == 0u && !in_box(sc, pos))) {
+                break;
+            }
+        }
+    }
+    advance[p] = make_float4(start.x, start.y, start.z, __uint_as_float(start_bits));
+}
+
+hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream)
+{
+    const dim3 grid((sc.width + 31) / 32, (sc.height + 7) / 8), block(256);
+    hipLaunchKernelGGL(primary_advance_kernel, grid, block, 0, stream, sc, primary, advance);
+    return hipGetLastError();
 }
 
 // Persistent wave-scheduled estimator.  Every lane owns one path at a time; a wave repeatedly
@@ -696,6 +771,14 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                             stepv = scale3(dir, sc.sample_step);
                             inv_maxd = inv_max_advance(sc, stepv);
                             dfree = 0;
+                            if (MODE != 1 && ba.advance) {
+                                // the pixel's pre-walked prefix (primary_advance_kernel)
+                                const float4 a = ba.advance[pixel];
+                                const uint32_t bits = __float_as_uint(a.w);
+                                pos = mk3(a.x, a.y, a.z);
+                                dfree = bits >> 24;
+                                c_dl += bits & 0x00ffffffu;
+                            }
                             state = ST_MARCH;
                         } else {
                             ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
@@ -782,19 +865,8 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 // in the same order -> bit-identical path).  They still count as density lookups:
                 // the counter is the algorithm's lookup count, not the loads this kernel issued.
                 if (dfree != 0u) {
-                    const int n = (int)(((float)dfree - 0.03125f) * inv_maxd);
-                    // the adds are the work; a wave-level branch per add is not: blocks of 8, then singles
-                    // (measured: 1815 -> 1891 Msamples/s; 16/4/1 is no better)
-                    int i = 0;
-                    for (; i + 8 <= n; i += 8) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            pos = add3(pos, stepv);
-                        }
-                    }
-                    for (; i < n; i++) {
-                        pos = add3(pos, stepv);
-                    }
+                    const int n = skip_steps(dfree, inv_maxd);
+                    replay_steps(pos, stepv, n);
                     c_dl += (uint32_t)n;
                     if (STATS) {
                         st_skip += (uint32_t)n;

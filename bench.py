@@ -146,6 +146,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # No garbage collection from here on (a full collection takes 20-30 ms with torch imported).
+    import gc
+    gc.collect()
+    gc.disable()
     nxt = 1
     for _ in range(args.warmup):
         step(nxt)
@@ -153,12 +157,25 @@ def main():
     k0 = tr.counters()
     r0, a0, l0 = tr.kernel_time()
     fence()
+    # The first GPU submission after the device-wide synchronize above was seen to start 20-30 ms late in
+    # most runs (first timed step 130-139 ms instead of 109, every kernel duration unchanged, gone under
+    # rocprofv3); a one-element torch op absorbs that wake-up before the clock starts.  It does no work of
+    # the benchmark, and the timed region is still bracketed by a synchronize on both sides.
+    torch.zeros(1, device="cuda").add_(1)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         step(nxt)
         nxt += S
+        step_marks.append(time.perf_counter() - t0)   # host time after the call (a waited-for step has finished)
+        if os.environ.get("CT_BENCH_VERBOSE") and not args.pipelined:
+            step_marks.append(tr.kernel_time()[0])
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("CT_BENCH_VERBOSE") and rank == 0:
+        print("step end marks (ms) [and cumulative kernel ms]:", ["%.2f" % (m * 1e3 if m < 50 else m) for m in step_marks], "total %.2f" % (elapsed * 1e3), file=sys.stderr)
     k1 = tr.counters()
     r1, a1, l1 = tr.kernel_time()
 

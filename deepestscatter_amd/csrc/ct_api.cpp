@@ -6,6 +6,7 @@
 // wrappers.  No exception leaves this file and nothing here falls back to a CPU path: if
 // HIP or the device is missing every entry point reports CT_E_NODEVICE / CT_E_HIP.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -61,6 +62,7 @@ struct CtHandle_ {
     uint32_t *d_job_group = nullptr, *d_job_sub = nullptr; // job list of the current batch size
     uint32_t n_groups = 0, groups_capacity = 0;
     uint32_t n_jobs = 0, jobs_capacity = 0, jobs_S = 0;
+    uint32_t jobs_hint = 0;           // batch size the caller asked for last (job lists are built for it)
     uint32_t q_begin[kQueues + 2] = {}; // job ranges of the per-XCD queues + the shared one
     uint64_t own_pixels = 0, hit_pixels = 0;
     bool queue_dirty = true, order_tuned = false;
@@ -339,6 +341,10 @@ static int create_impl(const CtScene *s, CtHandle h)
     }
     if (const char *e = getenv("CT_XCD_QUEUES")) {
         h->queues_enabled = atoi(e) != 0;
+    }
+    d.burst_march_min = 1;
+    if (const char *e = getenv("CT_BURST_MARCH_MIN")) {
+        d.burst_march_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     }
     d.tail_burst = 1;
     if (const char *e = getenv("CT_TAIL_BURST")) {
@@ -680,9 +686,10 @@ static int rebuild_queue(CtHandle h)
 // one-subframe jobs, cheap groups up to 8 subframes per job.
 static int build_jobs(CtHandle h, uint32_t S)
 {
-    if (h->jobs_S == S) {
-        return CT_OK;
+    if (h->jobs_S >= S) {
+        return CT_OK; // a list for a larger batch serves a smaller one (the kernel clips the jobs)
     }
+    S = std::max(S, h->jobs_hint);
     // One queue per XCD: groups are in tile-Morton order, so a contiguous range of them is a
     // compact image region whose paths read a compact part of the volume.  The ranges are cut at
     // equal shares of the measured cost (path depth + the primary march), not of the pixel count.
@@ -832,6 +839,10 @@ static int ensure_frames(CtHandle h, CtHandle_::Slot &sl, uint32_t S)
         sl.capacity = 0;
     }
     HIPCHK(h, dmalloc(&sl.frames, need));
+    // touch it now: the first launch that writes a fresh part of a large allocation has been seen to
+    // take 30 ms longer (measured on the 3.5 GB scratch of a 256-subframe batch)
+    HIPCHK(h, hipMemsetAsync(sl.frames, 0, need * sizeof(float4), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     sl.capacity = need;
     return CT_OK;
 }
@@ -843,10 +854,14 @@ static int collect(CtHandle h, CtHandle_::Slot &sl)
         return CT_OK;
     }
     sl.pending = false;
-    HIPCHK(h, hipEventSynchronize(sl.accumulated ? sl.ev_acc1 : sl.ev_done));
+    hipEvent_t last = sl.accumulated ? sl.ev_acc1 : sl.ev_done;
+    HIPCHK(h, hipEventSynchronize(last));
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_start, sl.ev_done));
     h->render_ms += ms;
+    if (getenv("CT_TRACE")) {
+        fprintf(stderr, "[cloudtrace] estimator launch %.2f ms\n", ms);
+    }
     if (sl.accumulated) {
         // from the end of the estimator launch (the accumulate kernel waits for exactly that) to the end
         // of the accumulate kernel; an event recorded on the main stream behind the wait is stamped too early
@@ -949,7 +964,7 @@ static int prepare_batches(CtHandle h, uint32_t S)
     if (simple) {
         return CT_OK;
     }
-    if (h->queue_dirty || h->jobs_S != S) {
+    if (h->queue_dirty || h->jobs_S < S) {
         int rc = flush(h);
         if (rc == CT_OK && h->queue_dirty) {
             rc = rebuild_queue(h);
@@ -1060,6 +1075,7 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
     uint32_t done = 0;
     while (done < count) {
         uint32_t S = (uint32_t)std::min<uint64_t>(cap, count - done);
+        h->jobs_hint = S;
         int rc;
         if (!simple && !h->order_tuned) {
             // the first launch of a pose measures the job costs (two atomics per path, jobs in image
@@ -1070,7 +1086,13 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
                 rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
             }
         } else {
+            const bool trace = getenv("CT_TRACE") != nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
             rc = prepare_batches(h, S);
+            const auto t1 = std::chrono::steady_clock::now();
+            if (wait) {
+                h->next_slot = 0; // synchronous batches never need the second slot (nor its scratch buffer)
+            }
             CtHandle_::Slot &sl = h->slots[h->next_slot];
             if (rc == CT_OK) {
                 rc = collect(h, sl); // at most two batches in flight: wait for the one that used this slot
@@ -1078,10 +1100,19 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             if (rc == CT_OK) {
                 rc = ensure_frames(h, sl, S);
             }
+            const auto t2 = std::chrono::steady_clock::now();
             if (rc == CT_OK) {
                 rc = submit_batch(h, sl, sl.frames, first_subframe_id + done, S, true);
             }
-            h->next_slot ^= 1;
+            if (trace) {
+                const auto t3 = std::chrono::steady_clock::now();
+                auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                fprintf(stderr, "[cloudtrace] batch first=%u S=%u: prepare %.2f ms, slot %.2f ms, submit %.2f ms\n",
+                        first_subframe_id + done, S, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+            }
+            if (!wait) {
+                h->next_slot ^= 1;
+            }
         }
         if (rc != CT_OK) {
             flush(h);

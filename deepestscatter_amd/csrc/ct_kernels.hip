@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
     uint32_t c_dl = 0, c_il = 0, c_cap = 0; // per-lane tallies
     // scheduler diagnostics (STATS builds only), see ct_debug_stats
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
-    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0, st_iters = 0;
+    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0, st_iters = 0, st_first = 0;
 
     const unsigned long long t_start = STATS ? wall_clock64() : 0ull; // 100 MHz
     unsigned long long t_drained = 0;
@@ -724,7 +724,8 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                     job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
                     job_s0 = sub & 0xffffu;
                     q_next = 0;
-                    q_end = (sub >> 16) * 64u;
+                    // the list may have been built for a larger batch: clip the job to this launch's subframes
+                    q_end = (job_s0 < ba.S ? min(sub >> 16, ba.S - job_s0) : 0u) * 64u;
                 }
             }
             if (q_next != q_end) {
@@ -886,6 +887,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 c_dl += 1;
                 work += 1u;
                 if (STATS) {
+                    st_first += (depth <= 1u) ? 1u : 0u;
                     st_fetch += 1;
                     st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
                     st_zero_d0 += ((cell.x | cell.y) == 0u && dfree == 0u) ? 1u : 0u;
@@ -922,7 +924,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             }
             const uint32_t m_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_MARCH));
             const uint32_t b_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_BOUNCE));
-            if (m_now == 0u || b_now >= sc.burst_scatter || 64u - m_now - b_now >= sc.burst_idle) {
+            if (m_now < sc.burst_march_min || b_now >= sc.burst_scatter || 64u - m_now - b_now >= sc.burst_idle) {
                 break;
             }
             if (STATS) {
@@ -976,7 +978,14 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             atomicAdd(&ba.stats[9], (unsigned long long)sv[3]);
             atomicAdd(&ba.stats[10], (unsigned long long)sv[4]);
             atomicAdd(&ba.stats[11], (unsigned long long)sv[5]);
-            atomicAdd(&ba.stats[12], (unsigned long long)(xcd_id() == (blockIdx.x & (uint32_t)(kQueues - 1)) ? 1u : 0u));
+            {
+                uint32_t v = st_first;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    v += __shfl_xor(v, off);
+                }
+                atomicAdd(&ba.stats[12], (unsigned long long)v);
+            }
             atomicAdd(&ba.stats[13], 1ull);
             atomicAdd(&ba.stats[14], (unsigned long long)st_stolen);
             atomicMax(&ba.stats[15], (unsigned long long)st_iters);
@@ -1221,7 +1230,8 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
                     job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
                     job_s0 = sub & 0xffffu;
                     q_next = 0;
-                    q_end = (sub >> 16) * 64u;
+                    // the list may have been built for a larger batch: clip the job to this launch's subframes
+                    q_end = (job_s0 < ba.S ? min(sub >> 16, ba.S - job_s0) : 0u) * 64u;
                 }
             }
             if (q_next != q_end) {

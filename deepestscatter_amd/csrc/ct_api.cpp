@@ -346,7 +346,7 @@ static int create_impl(const CtScene *s, CtHandle h)
     if (const char *e = getenv("CT_BURST_MARCH_MIN")) {
         d.burst_march_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     }
-    d.tail_burst = 1;
+    d.tail_burst = 8;
     if (const char *e = getenv("CT_TAIL_BURST")) {
         d.tail_burst = (uint32_t)std::min(1024, std::max(1, atoi(e)));
     }
@@ -814,6 +814,24 @@ static int tune_order(CtHandle h, uint32_t measured_subframes)
         }
         return log2_class(cost[a]) > log2_class(cost[b]);
     });
+    if (getenv("CT_STATS")) {
+        // share of the measured cost by class of the deepest path seen
+        std::vector<double> share(34, 0.0);
+        std::vector<uint32_t> count(34, 0);
+        double total = 0;
+        for (uint32_t g = 0; g < h->n_groups; g++) {
+            share[log2_class(deepest[g])] += cost[g];
+            count[log2_class(deepest[g])] += 1;
+            total += cost[g];
+        }
+        fprintf(stderr, "[cloudtrace] cost share by deepest-path class (2^(k-1) <= depth < 2^k):");
+        for (int k = 0; k < 34; k++) {
+            if (count[k]) {
+                fprintf(stderr, " k=%d groups %u share %.1f%%;", k, count[k], 100.0 * share[k] / std::max(total, 1.0));
+            }
+        }
+        fprintf(stderr, "\n");
+    }
     h->jobs_S = 0; // rebuild the job list with the new order
     return CT_OK;
 }

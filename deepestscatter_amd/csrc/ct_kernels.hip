@@ -924,7 +924,13 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             }
             const uint32_t m_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_MARCH));
             const uint32_t b_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_BOUNCE));
-            if (m_now < sc.burst_march_min || b_now >= sc.burst_scatter || 64u - m_now - b_now >= sc.burst_idle) {
+            if (drained) {
+                // nothing left to regenerate, so idle lanes are no reason to leave the burst: what matters
+                // now is the latency of the surviving paths -- march until half of them wait for the scatter
+                if (m_now == 0u || 2u * b_now >= m_now + b_now) {
+                    break;
+                }
+            } else if (m_now < sc.burst_march_min || b_now >= sc.burst_scatter || 64u - m_now - b_now >= sc.burst_idle) {
                 break;
             }
             if (STATS) {

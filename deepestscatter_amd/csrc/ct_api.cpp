@@ -498,7 +498,7 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1 + kStatCount) * sizeof(unsigned long long), h->stream));
 
     HIPCHK(h, dmalloc(&h->d_primary, 2 * pixels));
-    HIPCHK(h, dmalloc(&h->d_advance, pixels));
+    HIPCHK(h, dmalloc(&h->d_advance, (s->estimator == CT_EST_DELTA ? 4 : 1) * pixels));
     HIPCHK(h, hipStreamSynchronize(h->stream));
 
     // ---- default pose: Camera.cpp:37-39 through sutil::calculateCameraVariables
@@ -616,7 +616,11 @@ static int rebuild_queue(CtHandle h)
     const uint32_t W = h->scene.width, H = h->scene.height;
     const size_t pixels = (size_t)W * H;
     HIPCHK(h, launch_primary_rays(h->dev, h->d_primary, h->stream));
-    HIPCHK(h, launch_primary_advance(h->dev, h->d_primary, h->d_advance, h->stream));
+    if (h->scene.estimator == CT_EST_DELTA) {
+        HIPCHK(h, launch_primary_advance_delta(h->dev, h->d_primary, h->d_advance, h->stream));
+    } else {
+        HIPCHK(h, launch_primary_advance(h->dev, h->d_primary, h->d_advance, h->stream));
+    }
     std::vector<float4> prim(2 * pixels);
     HIPCHK(h, hipMemcpyAsync(prim.data(), h->d_primary, prim.size() * sizeof(float4), hipMemcpyDeviceToHost,
                              h->stream));
@@ -913,7 +917,7 @@ static int submit_batch(CtHandle h, CtHandle_::Slot &sl, float4 *frames, uint32_
     ba.frames = frames;
     ba.frame_stride = (simple || dense) ? 0u : h->n_groups * 64u;
     ba.primary = h->d_primary;
-    ba.advance = (h->scene.estimator == CT_EST_MARCH && !h->no_advance) ? h->d_advance : nullptr;
+    ba.advance = h->no_advance ? nullptr : h->d_advance;
     ba.pixels = h->d_pixels;
     ba.job_group = h->d_job_group;
     ba.job_sub = h->d_job_sub;

@@ -21,8 +21,9 @@ struct BatchArgs {
     float4 *frames;
     uint32_t frame_stride;
     const float4 *primary;     // 2 float4 per pixel: cached primary ray (primary_rays_kernel)
-    const float4 *advance;     // per pixel: state after the pre-walked prefix of the primary march
-                               // (primary_advance_kernel); NULL = start at the entry point
+    const float4 *advance;     // per pixel: state after the pre-walked prefix of the primary flight: 1 float4
+                               // (MARCH, primary_advance_kernel) or 4 (DELTA, primary_advance_delta_kernel);
+                               // NULL = start at the entry point
     const uint32_t *pixels;    // this shard's box-hitting pixels, 64 per group, 0xffffffff padded
     // job list: job j renders subframes [begin, begin+count) of pixel group job_group[j];
     // job_sub[j] = begin | count << 16.  Sorted most expensive group first, and expensive groups
@@ -80,6 +81,7 @@ hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchSh
 hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream);
 hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream);
 hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);
+hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);
 hipError_t launch_fill_frame(float4 *frame, uint32_t width, uint32_t height, uint32_t shard_index,
                              uint32_t shard_count, hipStream_t stream);
 hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);

@@ -1203,6 +1203,49 @@ CT_DEV void dda_cross(Dda &d, f3 dir)
     }
 }
 
+// The DELTA twin of primary_advance_kernel: the brick DDA of a primary ray draws no random number before
+// it reaches the first brick with a non-zero majorant (or leaves the grid), so that walk is the same
+// for every sample of the pixel.  It is done once per pose with the tracking visit's own operations;
+// advance[4p .. 4p+3] = the Dda state a sample starts its first visit with.
+__global__ __launch_bounds__(256) void primary_advance_delta_kernel(DevScene sc, const float4 *__restrict__ primary,
+                                                                    float4 *__restrict__ advance)
+{
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
+    const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= sc.width || y >= sc.height) {
+        return;
+    }
+    const size_t p = (size_t)y * sc.width + x;
+    const float4 p0 = primary[2 * p], p1 = primary[2 * p + 1];
+    const f3 pos = mk3(p0.x, p0.y, p0.z), dir = mk3(p1.x, p1.y, p1.z);
+    Dda d{};
+    if (p0.w != 0.f && in_box(sc, pos)) {
+        dda_begin(sc, d, pos, dir);
+        for (int it = 0; it < 65536; it++) {
+            if (!brick_in_grid(sc, d) || (d.meta >> 8) != 0u) {
+                break;
+            }
+            const uint32_t D = d.meta & 0x7fu;
+            const uint32_t n = D > 1u ? D - 1u : 1u;
+            for (uint32_t i = 0; i < n; i++) {
+                dda_cross(d, dir);
+            }
+            d.meta = brick_in_grid(sc, d) ? load_brick_meta(sc, d.bx, d.by, d.bz) : 0u;
+        }
+    }
+    advance[4 * p] = make_float4(d.org.x, d.org.y, d.org.z, d.t);
+    advance[4 * p + 1] = make_float4(d.tmax.x, d.tmax.y, d.tmax.z, __int_as_float(d.bx));
+    advance[4 * p + 2] = make_float4(d.tdelta.x, d.tdelta.y, d.tdelta.z, __int_as_float(d.by));
+    advance[4 * p + 3] = make_float4(__int_as_float(d.bz), __uint_as_float(d.meta), 0.f, 0.f);
+}
+
+hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream)
+{
+    const dim3 grid((sc.width + 31) / 32, (sc.height + 7) / 8), block(256);
+    hipLaunchKernelGGL(primary_advance_delta_kernel, grid, block, 0, stream, sc, primary, advance);
+    return hipGetLastError();
+}
+
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArgs ba)
 {
@@ -1277,7 +1320,21 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
                             }
                         }
                         if (go) {
-                            dda_begin(sc, dda, pos, dir);
+                            if (MODE != 1 && ba.advance) {
+                                // the pixel's pre-walked DDA prefix (primary_advance_delta_kernel)
+                                const float4 a0 = ba.advance[4 * (size_t)pixel], a1 = ba.advance[4 * (size_t)pixel + 1];
+                                const float4 a2 = ba.advance[4 * (size_t)pixel + 2], a3 = ba.advance[4 * (size_t)pixel + 3];
+                                dda.org = mk3(a0.x, a0.y, a0.z);
+                                dda.t = a0.w;
+                                dda.tmax = mk3(a1.x, a1.y, a1.z);
+                                dda.bx = __float_as_int(a1.w);
+                                dda.tdelta = mk3(a2.x, a2.y, a2.z);
+                                dda.by = __float_as_int(a2.w);
+                                dda.bz = __float_as_int(a3.x);
+                                dda.meta = __float_as_uint(a3.y);
+                            } else {
+                                dda_begin(sc, dda, pos, dir);
+                            }
                             state = ST_MARCH;
                         } else {
                             ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);

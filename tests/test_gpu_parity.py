@@ -486,6 +486,29 @@ def test_sharded_tracer_staged_async_path_single_rank():
     ref.close()
 
 
+def test_error_behaviour_of_the_newer_entry_points():
+    """Descriptor gather, async batches: argument checks and state errors come back as CtStatus codes."""
+    tex = sphere_volume(16)
+    tr = ds.CloudTracer(tex, width=16, height=16)
+    with pytest.raises(_lib.CloudTraceError) as e:
+        tr.render_accumulate_async(3, 2)                 # out of order
+    assert e.value.code == _lib.CT_E_STATE
+    with pytest.raises(ValueError):
+        tr.collect_descriptors(np.zeros((2, 3), np.float32), np.zeros((3, 3), np.float32))
+    L = _lib.load()
+    assert L.ct_collect_descriptors(tr.h, None, None, 4, None) == _lib.CT_E_INVAL
+    assert L.ct_collect_descriptors(tr.h, None, None, 0, None) == _lib.CT_E_INVAL
+    assert L.ct_copy_to_device_async(tr.h, _lib.CT_BUF_MEAN, None, 16 * 16 * 16) == _lib.CT_E_INVAL
+    assert L.ct_synchronize(None) == _lib.CT_E_INVAL
+    tr.render_accumulate_async(1, 2)                     # still usable
+    tr.synchronize()
+    assert tr.subframes == 2
+    # a descriptor far outside the box is all zero; one at the centre of a cloud is not
+    d = tr.collect_descriptors([[5.0, 5.0, 5.0], [0.0, 0.0, 0.0]], [[0, 0, 1], [0, 0, 1]])
+    assert not d[0].any() and d[1].any()
+    tr.close()
+
+
 def test_descriptors_bit_exact_vs_oracle():
     """ct_collect_descriptors (setupHierarchicalDescriptor, DisneyDescriptor.cuh:71-112): the mip pyramid,
     the mip-linear trilinear sampler, the light/view frame and the fade outside the box, byte for byte."""

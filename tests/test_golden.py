@@ -63,3 +63,29 @@ def test_oracle_reproduces_golden_renders():
             c = o.counters.as_dict()
             assert [c[k] for k in ("paths", "box_hits", "density_lookups", "inscatter_lookups", "scatter_events",
                                    "depth_capped")] == case["counters"]
+
+
+GOLDEN_V2 = Path(__file__).resolve().parent / "golden" / "golden_v2.npz"
+COUNTER_KEYS = ("paths", "box_hits", "density_lookups", "inscatter_lookups", "scatter_events", "depth_capped")
+
+
+def test_oracle_reproduces_golden_v2():
+    """golden_v2.npz (tools/make_golden.py): DELTA estimator, scatter-sample generator, hierarchical
+    descriptors, point-radiance tasks."""
+    z = np.load(GOLDEN_V2)
+    for entry in z["delta_case_names"]:
+        cname, vname = str(entry).split(":")
+        mode, w, h, spp = (int(v) for v in z[f"case_{cname}_meta"])
+        o = O.Oracle(z[f"vol_{vname}"], w, h, mode=mode, estimator=1)
+        mean, m2 = o.render(spp)
+        assert np.array_equal(mean, z[f"case_{cname}_mean"]) and np.array_equal(m2, z[f"case_{cname}_m2"])
+        c = o.counters.as_dict()
+        assert [c[k] for k in COUNTER_KEYS] == [int(v) for v in z[f"case_{cname}_counters"]]
+    o = O.Oracle(z["vol_v0"], 8, 8, mode=1, cloud_size_m=700.0)
+    pos, view = o.generate_scatter_samples(12, batch_seed=7)
+    assert np.array_equal(pos, z["samples_pos"]) and np.array_equal(view, z["samples_dir"])
+    assert np.array_equal(o.collect_descriptors(pos, view), z["descriptors"])
+    from deepestscatter_amd.cloudtrace import make_point_tasks
+    tasks = make_point_tasks(pos, view)
+    o.point_radiance_launch(tasks, 1, 6)
+    assert np.array_equal(tasks.view(np.uint8).reshape(len(tasks), 40), z["point_tasks"])

@@ -548,6 +548,31 @@ def test_golden_fixture_on_gpu():
 
 
 # ---- full-size properties (BASELINE.json config 2: 512^3 volume, 1024^2 frame) -------------------------
+def test_golden_v2_fixture_on_gpu():
+    """tests/golden/golden_v2.npz through the HIP path: DELTA renders, generated scatter samples, descriptors
+    and point-radiance tasks, bit for bit."""
+    from test_golden import GOLDEN_V2, COUNTER_KEYS
+    from deepestscatter_amd.cloudtrace import make_point_tasks
+    z = np.load(GOLDEN_V2)
+    for entry in z["delta_case_names"]:
+        cname, vname = str(entry).split(":")
+        mode, w, h, spp = (int(v) for v in z[f"case_{cname}_meta"])
+        tr = ds.CloudTracer(z[f"vol_{vname}"], width=w, height=h, mode=mode, estimator=1)
+        tr.render_accumulate(1, spp)
+        assert np.array_equal(tr.mean(), z[f"case_{cname}_mean"]) and np.array_equal(tr.m2(), z[f"case_{cname}_m2"])
+        c = tr.counters()
+        assert [c[k] for k in COUNTER_KEYS] == [int(v) for v in z[f"case_{cname}_counters"]]
+        tr.close()
+    tr = ds.CloudTracer(z["vol_v0"], width=8, height=8, mode=1, cloud_size_m=700.0)
+    pos, view = tr.generate_scatter_samples(12, batch_seed=7)
+    assert np.array_equal(pos, z["samples_pos"]) and np.array_equal(view, z["samples_dir"])
+    assert np.array_equal(tr.collect_descriptors(pos, view), z["descriptors"])
+    tasks = make_point_tasks(pos, view)
+    tr.point_radiance_launch(tasks, 1, 6)
+    assert np.array_equal(tasks.view(np.uint8).reshape(len(tasks), 40), z["point_tasks"])
+    tr.close()
+
+
 def test_full_size_properties_512_1024():
     n = 512
     tex = ds.make_procedural_cloud(n)

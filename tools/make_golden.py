@@ -16,6 +16,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
 import _oracle as O  # noqa: E402
 
 OUT = ROOT / "tests" / "golden" / "golden_v1.npz"
@@ -72,6 +73,34 @@ def main():
     OUT.parent.mkdir(parents=True, exist_ok=True)
     np.savez_compressed(OUT, **data)
     print("wrote", OUT, OUT.stat().st_size, "bytes")
+    make_v2(vols)
+
+
+def make_v2(vols):
+    """golden_v2.npz: the rows added after v1 -- DELTA estimator, scatter-sample generator,
+    point-radiance tasks, hierarchical descriptors (SURVEY section 8 f)."""
+    out = ROOT / "tests" / "golden" / "golden_v2.npz"
+    data = {"vol_v0": vols["v0"], "vol_v1": vols["v1"]}
+    for cname, vname, mode, w, h, spp in (("delta_total_v0", "v0", 0, 16, 16, 4), ("delta_single_v1", "v1", 2, 24, 12, 8)):
+        o = O.Oracle(vols[vname], w, h, mode=mode, estimator=1)
+        mean, m2 = o.render(spp)
+        c = o.counters.as_dict()
+        data[f"case_{cname}_mean"], data[f"case_{cname}_m2"] = mean, m2
+        data[f"case_{cname}_counters"] = np.array(
+            [c[k] for k in ("paths", "box_hits", "density_lookups", "inscatter_lookups", "scatter_events",
+                            "depth_capped")], np.uint64)
+        data[f"case_{cname}_meta"] = np.array([mode, w, h, spp], np.int64)
+    data["delta_case_names"] = np.array(["delta_total_v0:v0", "delta_single_v1:v1"])
+    o = O.Oracle(vols["v0"], 8, 8, mode=1, cloud_size_m=700.0)
+    pos, view = o.generate_scatter_samples(12, batch_seed=7)
+    data["samples_pos"], data["samples_dir"] = pos, view
+    data["descriptors"] = o.collect_descriptors(pos, view)
+    from deepestscatter_amd.cloudtrace import make_point_tasks
+    tasks = make_point_tasks(pos, view)
+    o.point_radiance_launch(tasks, 1, 6)
+    data["point_tasks"] = tasks.view(np.uint8).reshape(len(tasks), 40)
+    np.savez_compressed(out, **data)
+    print("wrote", out, out.stat().st_size, "bytes")
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ EXPORTS = [
     "ct_create", "ct_destroy", "ct_last_error", "ct_set_stream", "ct_set_camera", "ct_render_subframe",
     "ct_accumulate", "ct_render_accumulate", "ct_render_accumulate_async", "ct_synchronize", "ct_copy_to_device_async", "ct_point_radiance_launch", "ct_generate_scatter_samples", "ct_collect_descriptors", "ct_reset", "ct_tonemap", "ct_is_converged", "ct_download",
     "ct_buffer_bytes", "ct_copy_to_device", "ct_device_ptr", "ct_subframes", "ct_set_subframes", "ct_counters", "ct_kernel_time",
-    "ct_debug_cdf_inversion", "ct_debug_fetch_probe", "ct_debug_stats", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_generate_mipmaps",
+    "ct_debug_cdf_inversion", "ct_debug_fetch_probe", "ct_debug_stats", "ct_debug_suspended", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_generate_mipmaps",
     "ct_tile_owner", "ct_make_procedural_cloud",
 ]
 
@@ -108,6 +108,7 @@ def load():
         "ct_buffer_bytes": (i32, [vp, i32, C.POINTER(C.c_size_t)]),
         "ct_copy_to_device": (i32, [vp, i32, vp, C.c_size_t]),
         "ct_copy_to_device_async": (i32, [vp, i32, vp, C.c_size_t]),
+        "ct_debug_suspended": (i32, [vp, vp]),
         "ct_device_ptr": (i32, [vp, i32, C.POINTER(vp)]),
         "ct_subframes": (i32, [vp, C.POINTER(u32)]),
         "ct_set_subframes": (i32, [vp, u32]),

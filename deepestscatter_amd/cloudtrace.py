@@ -326,6 +326,12 @@ class CloudTracer:
         d["wave_end_minus_drained_hist_0p5ms"] = [int(v) for v in out[40:64]]
         return d
 
+    def debug_suspended(self) -> int:
+        """Paths handed from one async launch to the next so far."""
+        n = C.c_uint64(0)
+        check(self.L.ct_debug_suspended(self.h, C.byref(n)), self.h)
+        return int(n.value)
+
     def debug_cdf_inversion(self, first_u24: int, count: int) -> np.ndarray:
         out = np.empty(count, np.uint32)
         check(self.L.ct_debug_cdf_inversion(self.h, first_u24, count, _p(out)), self.h)

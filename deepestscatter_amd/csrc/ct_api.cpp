@@ -40,20 +40,33 @@ struct CtHandle_ {
     uint16_t *d_guide = nullptr;
     float4 *d_frame = nullptr, *d_mean = nullptr, *d_m2 = nullptr;
     uchar4 *d_screen = nullptr;
-    // Two batches may be in flight (ct_render_accumulate_async): batch k+1's estimator kernel starts on
-    // its slot's stream while the last long paths of batch k are still running; the accumulate kernels
-    // stay in subframe order on the main stream.  A slot owns what a launch writes: the per-sample
-    // scratch [S][stride] (compact) or [S][H][W] (simple kernel) and the queue counters.
+    // Batches enqueued with ct_render_accumulate_async form a pipeline on the handle's stream:
+    //     R1  R2 A1  R3 A2  ...  (flush:) Rf An
+    // The estimator launch R(k) of the MARCH estimator does not run its surviving paths to their end when
+    // its job list is empty: it suspends them (BatchArgs::cont_out) and R(k+1) resumes them first, so no
+    // launch ends with a tail of waves that carry a few long paths each.  A(k), the accumulate kernel
+    // of batch k, therefore follows R(k+1) (or the flush launch Rf, which only resumes).  Two slots
+    // alternate: a slot owns the half of the per-sample scratch a batch writes ([S][stride] compact or
+    // [S][H][W] for the simple kernel), its queue counters, its buffer of suspended paths and its events.
     struct Slot {
-        float4 *frames = nullptr;
-        size_t capacity = 0; // in float4
         uint32_t *queue = nullptr;
-        hipStream_t stream = nullptr;
+        uint32_t *cont = nullptr;          // suspended paths written by this slot's launch
         hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_done = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr;
-        bool pending = false, accumulated = false;
+        bool pending = false;              // launched, kernel times not booked yet
+        bool accumulated = false;          // its accumulate kernel has been enqueued (ev_acc0/1 valid)
+        bool awaits_accumulate = false;    // launched with suspension: A(k) is still to be enqueued
+        bool suspended = false;            // launched with suspension, counter not read yet
+        uint32_t first = 0, S = 0;
     };
     Slot slots[2];
     int next_slot = 0;
+    float4 *d_frames_all = nullptr;        // both halves of the per-sample scratch
+    size_t slot_capacity = 0;              // float4 per half
+    uint32_t *d_cont_count = nullptr;      // [2] entries in slots[i].cont, [2] = resume cursor
+    size_t cont_capacity = 0;              // entries per slot
+    hipEvent_t ev_flush0 = nullptr, ev_flush1 = nullptr;
+    bool continuation = true;              // CT_CONTINUATION=0: async batches run every path to its end
+    uint64_t suspended_total = 0;          // paths handed from one launch to the next so far (ct_debug_suspended)
     // work queue of the persistent kernel (rebuilt when the camera moves)
     float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
     float4 *d_advance = nullptr;      // per pixel: pre-walked prefix of the primary march (MARCH estimator)
@@ -218,16 +231,11 @@ static void release(CtHandle h)
         return;
     }
     hipSetDevice(h->device);
-    for (auto &sl : h->slots) {
-        if (sl.stream) {
-            hipStreamSynchronize(sl.stream);
-        }
-    }
     if (h->stream) {
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->slots[0].frames, h->slots[1].frames, h->slots[0].queue, h->slots[1].queue, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->slots[0].queue, h->slots[1].queue, h->slots[0].cont, h->slots[1].cont, h->d_cont_count, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
         if (p) {
@@ -245,8 +253,10 @@ static void release(CtHandle h)
                 hipEventDestroy(e);
             }
         }
-        if (sl.stream) {
-            hipStreamDestroy(sl.stream);
+    }
+    for (hipEvent_t e : { h->ev_flush0, h->ev_flush1 }) {
+        if (e) {
+            hipEventDestroy(e);
         }
     }
     if (h->own_stream) {
@@ -345,6 +355,11 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.burst_march_min = 1;
     if (const char *e = getenv("CT_BURST_MARCH_MIN")) {
         d.burst_march_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
+    }
+    d.hint_period = 64;
+    if (const char *e = getenv("CT_HINT_PERIOD")) {
+        const int v = atoi(e);
+        d.hint_period = (v > 0 && (v & (v - 1)) == 0) ? (uint32_t)v : 0u;
     }
     d.tail_burst = 8;
     if (const char *e = getenv("CT_TAIL_BURST")) {
@@ -482,10 +497,20 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, dmalloc(&h->d_screen, pixels));
     HIPCHK(h, dmalloc(&h->d_colsum, s->width));
     HIPCHK(h, dmalloc(&h->d_avg, 1));
-    HIPCHK(h, dmalloc(&h->d_queue, kQueues + 1));
+    HIPCHK(h, dmalloc(&h->d_queue, kQueueWords));
+    HIPCHK(h, dmalloc(&h->d_cont_count, 3));
+    HIPCHK(h, hipMemsetAsync(h->d_cont_count, 0, 3 * sizeof(uint32_t), h->stream));
+    // a lane suspends the path it carries when the job list runs empty, and once more per sample that is left
+    // in its wave's last job (at most 8 x 64 samples spread over 64 lanes)
+    h->cont_capacity = (size_t)h->shape.blocks * h->shape.threads * 10;
+    HIPCHK(h, hipEventCreate(&h->ev_flush0));
+    HIPCHK(h, hipEventCreate(&h->ev_flush1));
+    if (const char *e = getenv("CT_CONTINUATION")) {
+        h->continuation = atoi(e) != 0;
+    }
     for (auto &sl : h->slots) {
-        HIPCHK(h, dmalloc(&sl.queue, kQueues + 1));
-        HIPCHK(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        HIPCHK(h, dmalloc(&sl.cont, h->cont_capacity * kContWords));
+        HIPCHK(h, dmalloc(&sl.queue, kQueueWords));
         for (hipEvent_t *e : { &sl.ev_in, &sl.ev_start, &sl.ev_done, &sl.ev_acc0, &sl.ev_acc1 }) {
             HIPCHK(h, hipEventCreate(e));
         }
@@ -849,73 +874,99 @@ static size_t frame_stride(CtHandle h)
     return (size_t)h->n_groups * 64;
 }
 
-static int ensure_frames(CtHandle h, CtHandle_::Slot &sl, uint32_t S)
+// Both halves of the per-sample scratch, each large enough for a batch of S subframes.
+static int ensure_frames(CtHandle h, uint32_t S)
 {
     const size_t need = std::max<size_t>((size_t)S * frame_stride(h), 1);
-    if (need <= sl.capacity) {
+    if (need <= h->slot_capacity) {
         return CT_OK;
     }
-    if (sl.frames) {
-        HIPCHK(h, hipFree(sl.frames));
-        sl.frames = nullptr;
-        sl.capacity = 0;
+    if (2 * need > 0xffffffffull) {
+        return fail(h, CT_E_INVAL, "batch of %u subframes is too large for 32-bit result indices", S);
     }
-    HIPCHK(h, dmalloc(&sl.frames, need));
+    if (h->d_frames_all) {
+        HIPCHK(h, hipFree(h->d_frames_all));
+        h->d_frames_all = nullptr;
+        h->slot_capacity = 0;
+    }
+    HIPCHK(h, dmalloc(&h->d_frames_all, 2 * need));
     // touch it now: the first launch that writes a fresh part of a large allocation has been seen to
     // take 30 ms longer (measured on the 3.5 GB scratch of a 256-subframe batch)
-    HIPCHK(h, hipMemsetAsync(sl.frames, 0, need * sizeof(float4), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_frames_all, 0, 2 * need * sizeof(float4), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    sl.capacity = need;
+    h->slot_capacity = need;
     return CT_OK;
 }
 
-// Waits for one slot's batch (estimator + accumulate) and books its kernel times.
+static float4 *slot_frames(CtHandle h, int slot)
+{
+    return h->d_frames_all + (size_t)slot * h->slot_capacity;
+}
+
+// Waits for one slot's launch (and its accumulate kernel, if enqueued) and books the kernel times.
 static int collect(CtHandle h, CtHandle_::Slot &sl)
 {
     if (!sl.pending) {
         return CT_OK;
     }
     sl.pending = false;
-    hipEvent_t last = sl.accumulated ? sl.ev_acc1 : sl.ev_done;
-    HIPCHK(h, hipEventSynchronize(last));
+    HIPCHK(h, hipEventSynchronize(sl.accumulated ? sl.ev_acc1 : sl.ev_done));
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_start, sl.ev_done));
     h->render_ms += ms;
     if (getenv("CT_TRACE")) {
-        fprintf(stderr, "[cloudtrace] estimator launch %.2f ms\n", ms);
+        uint32_t cnt[3] = { 0, 0, 0 };
+        hipMemcpy(cnt, h->d_cont_count, sizeof cnt, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[cloudtrace] estimator launch %.2f ms (suspended paths per slot now: %u %u, cursor %u)\n", ms,
+                cnt[0], cnt[1], cnt[2]);
     }
     if (sl.accumulated) {
-        // from the end of the estimator launch (the accumulate kernel waits for exactly that) to the end
-        // of the accumulate kernel; an event recorded on the main stream behind the wait is stamped too early
-        HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_done, sl.ev_acc1));
+        HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_acc0, sl.ev_acc1));
         h->accum_ms += ms;
     }
     h->launches += 1;
-    return CT_OK;
-}
-
-// Every batch in flight has finished when this returns (oldest first).
-static int flush(CtHandle h)
-{
-    for (int k = 0; k < 2; k++) {
-        const int rc = collect(h, h->slots[(h->next_slot + k) & 1]);
-        if (rc != CT_OK) {
-            return rc;
-        }
+    if (sl.suspended) {
+        uint32_t n = 0;
+        HIPCHK(h, hipMemcpy(&n, h->d_cont_count + (&sl - h->slots), sizeof n, hipMemcpyDeviceToHost));
+        h->suspended_total += n;
+        sl.suspended = false;
     }
     return CT_OK;
 }
 
-// Enqueues one launch of the estimator over S subframes into `frames` (the slot's scratch, or the
-// dense frame buffer for ct_render_subframe) on the slot's stream, and the accumulate kernel on the
-// main stream behind it.  Does not wait.
-static int submit_batch(CtHandle h, CtHandle_::Slot &sl, float4 *frames, uint32_t first, uint32_t S, bool accumulate)
+static int enqueue_accumulate(CtHandle h, CtHandle_::Slot &sl, const float4 *frames, bool dense)
 {
     const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
-    const bool dense = (frames == h->d_frame);
+    HIPCHK(h, hipEventRecord(sl.ev_acc0, h->stream));
+    if (simple || dense) {
+        HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width, h->scene.height,
+                                          h->scene.shard_index, h->scene.shard_count, h->stream));
+    } else {
+        HIPCHK(h, launch_accumulate_list(frames, h->n_groups * 64u, h->d_pixels, h->n_groups * 64u, h->d_primary,
+                                         h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width, h->scene.height,
+                                         h->scene.shard_index, h->scene.shard_count, h->stream));
+    }
+    HIPCHK(h, hipEventRecord(sl.ev_acc1, h->stream));
+    sl.accumulated = true;
+    sl.awaits_accumulate = false;
+    return CT_OK;
+}
+
+// Enqueues one launch of the estimator over S subframes.  `frames` is the dense frame buffer
+// (ct_render_subframe) or NULL for the slot's half of the scratch.  With `suspend` the launch hands its
+// surviving paths to the next one and the accumulate kernel is left to the caller's successor; the
+// paths the other slot's launch suspended are resumed in any case.  Does not wait.
+static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t first, uint32_t S, bool accumulate,
+                        bool suspend)
+{
+    CtHandle_::Slot &sl = h->slots[slot];
+    CtHandle_::Slot &other = h->slots[slot ^ 1];
+    const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
+    const bool dense = dense_frames != nullptr;
     BatchArgs ba{};
-    ba.frames = frames;
+    ba.frames = dense ? dense_frames : (simple ? slot_frames(h, slot) : h->d_frames_all);
     ba.frame_stride = (simple || dense) ? 0u : h->n_groups * 64u;
+    ba.out_offset = (simple || dense) ? 0u : (uint32_t)((size_t)slot * h->slot_capacity);
     ba.primary = h->d_primary;
     ba.advance = h->no_advance ? nullptr : h->d_advance;
     ba.pixels = h->d_pixels;
@@ -932,50 +983,114 @@ static int submit_batch(CtHandle h, CtHandle_::Slot &sl, float4 *frames, uint32_
     ba.queue = sl.queue;
     ba.counters = h->d_counters;
     ba.stats = h->d_counters + kCounterCount + 1;
-    if (dense) {
-        // ct_render_subframe: the main stream has just initialised the frame buffer.  (Batches into a
-        // slot's own scratch must NOT wait for the main stream: that is where the previous batch's
-        // accumulate kernel sits, behind the previous estimator launch.)
-        HIPCHK(h, hipEventRecord(sl.ev_in, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(sl.stream, sl.ev_in, 0));
+    if (other.awaits_accumulate) {
+        ba.cont_in = other.cont;
+        ba.cont_in_count = h->d_cont_count + (slot ^ 1);
+        ba.cont_cursor = h->d_cont_count + 2;
+        HIPCHK(h, hipMemsetAsync(h->d_cont_count + 2, 0, sizeof(uint32_t), h->stream));
     }
-    HIPCHK(h, hipMemsetAsync(sl.queue, 0, (kQueues + 1) * sizeof(uint32_t), sl.stream));
-    HIPCHK(h, hipEventRecord(sl.ev_start, sl.stream));
+    if (suspend) {
+        ba.cont_out = sl.cont;
+        ba.cont_out_count = h->d_cont_count + slot;
+        HIPCHK(h, hipMemsetAsync(h->d_cont_count + slot, 0, sizeof(uint32_t), h->stream));
+    }
+    HIPCHK(h, hipMemsetAsync(sl.queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipEventRecord(sl.ev_start, h->stream));
     if (simple) {
         for (uint32_t s = 0; s < S; s++) {
             BatchArgs one = ba;
-            one.frames = frames + (size_t)s * h->scene.width * h->scene.height;
+            one.frames = ba.frames + (size_t)s * h->scene.width * h->scene.height;
             one.first_subframe = first + s;
             one.S = 1;
-            HIPCHK(h, launch_render_simple(h->dev, one, h->scene.shard_index, h->scene.shard_count, sl.stream));
+            HIPCHK(h, launch_render_simple(h->dev, one, h->scene.shard_index, h->scene.shard_count, h->stream));
         }
     } else {
-        if (h->n_jobs != 0) {
+        if (h->n_jobs != 0 || ba.cont_in) {
             if (h->scene.estimator == CT_EST_DELTA) {
-                HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, sl.stream));
+                HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
             } else {
-                HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, sl.stream));
+                HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
             }
         }
         h->host_paths += h->own_pixels * S;
         h->host_hits += h->hit_pixels * S;
     }
-    HIPCHK(h, hipEventRecord(sl.ev_done, sl.stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, sl.ev_done, 0));
-    sl.accumulated = accumulate;
-    if (accumulate) {
-        HIPCHK(h, hipEventRecord(sl.ev_acc0, h->stream));
-        if (simple || dense) {
-            HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, first, S, h->scene.width, h->scene.height,
-                                              h->scene.shard_index, h->scene.shard_count, h->stream));
-        } else {
-            HIPCHK(h, launch_accumulate_list(frames, ba.frame_stride, h->d_pixels, h->n_groups * 64u, h->d_primary,
-                                             h->d_mean, h->d_m2, first, S, h->scene.width, h->scene.height,
-                                             h->scene.shard_index, h->scene.shard_count, h->stream));
-        }
-        HIPCHK(h, hipEventRecord(sl.ev_acc1, h->stream));
-    }
+    HIPCHK(h, hipEventRecord(sl.ev_done, h->stream));
+    sl.first = first;
+    sl.S = S;
     sl.pending = true;
+    sl.accumulated = false;
+    sl.awaits_accumulate = false;
+    sl.suspended = suspend;
+    // the batch whose suspended paths this launch has just finished can be accumulated now
+    if (other.awaits_accumulate) {
+        const int rc = enqueue_accumulate(h, other, slot_frames(h, slot ^ 1), false);
+        if (rc != CT_OK) {
+            return rc;
+        }
+    }
+    if (accumulate) {
+        if (suspend) {
+            sl.awaits_accumulate = true;
+        } else {
+            const int rc = enqueue_accumulate(h, sl, dense ? dense_frames : slot_frames(h, slot), dense);
+            if (rc != CT_OK) {
+                return rc;
+            }
+        }
+    }
+    return CT_OK;
+}
+
+// Every batch in flight has finished when this returns.  A batch that is still waiting for its suspended
+// paths gets a launch that only resumes them (no jobs), then its accumulate kernel.
+static int flush(CtHandle h)
+{
+    for (int slot = 0; slot < 2; slot++) {
+        CtHandle_::Slot &sl = h->slots[slot];
+        if (!sl.awaits_accumulate) {
+            continue;
+        }
+        BatchArgs ba{};
+        ba.frames = h->d_frames_all;
+        ba.frame_stride = h->n_groups * 64u;
+        ba.primary = h->d_primary;
+        ba.advance = h->no_advance ? nullptr : h->d_advance;
+        ba.pixels = h->d_pixels;
+        ba.job_group = h->d_job_group;
+        ba.job_sub = h->d_job_sub;
+        ba.n_jobs = 0;                  // q_begin stays all zero: every queue is empty
+        ba.first_subframe = sl.first;
+        ba.S = sl.S;
+        ba.queue = h->d_queue;
+        ba.counters = h->d_counters;
+        ba.stats = h->d_counters + kCounterCount + 1;
+        ba.cont_in = sl.cont;
+        ba.cont_in_count = h->d_cont_count + slot;
+        ba.cont_cursor = h->d_cont_count + 2;
+        HIPCHK(h, hipMemsetAsync(h->d_cont_count + 2, 0, sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipEventRecord(h->ev_flush0, h->stream));
+        HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+        HIPCHK(h, hipEventRecord(h->ev_flush1, h->stream));
+        const int rc = enqueue_accumulate(h, sl, slot_frames(h, slot), false);
+        if (rc != CT_OK) {
+            return rc;
+        }
+        HIPCHK(h, hipEventSynchronize(h->ev_flush1));
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev_flush0, h->ev_flush1));
+        h->render_ms += ms; // the launch that only resumes belongs to the estimator's time
+        if (getenv("CT_TRACE")) {
+            fprintf(stderr, "[cloudtrace] resume-only launch %.2f ms\n", ms);
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        const int rc = collect(h, h->slots[(h->next_slot + k) & 1]);
+        if (rc != CT_OK) {
+            return rc;
+        }
+    }
     return CT_OK;
 }
 
@@ -999,8 +1114,9 @@ static int prepare_batches(CtHandle h, uint32_t S)
     return CT_OK;
 }
 
-// One launch of the estimator over S subframes into `frames` (+ optional accumulate), waited for.
-static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, bool accumulate)
+// One launch of the estimator over S subframes (+ optional accumulate), waited for.  `dense_frames` is
+// the frame buffer of ct_render_subframe or NULL for the batch scratch.
+static int run_batch(CtHandle h, float4 *dense_frames, uint32_t first, uint32_t S, bool accumulate)
 {
     int rc = flush(h);
     if (rc == CT_OK) {
@@ -1009,10 +1125,9 @@ static int run_batch(CtHandle h, float4 *frames, uint32_t first, uint32_t S, boo
     if (rc != CT_OK) {
         return rc;
     }
-    CtHandle_::Slot &sl = h->slots[0];
-    rc = submit_batch(h, sl, frames ? frames : sl.frames, first, S, accumulate);
+    rc = submit_batch(h, 0, dense_frames, first, S, accumulate, false);
     if (rc == CT_OK) {
-        rc = collect(h, sl);
+        rc = collect(h, h->slots[0]);
     }
     if (rc != CT_OK) {
         return rc;
@@ -1102,7 +1217,10 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
         if (!simple && !h->order_tuned) {
             // the first launch of a pose measures the job costs (two atomics per path, jobs in image
             // order): it is kept short, waited for, then the order is set
-            rc = ensure_frames(h, h->slots[0], S); // sized for the batches that follow, not for this short one
+            rc = flush(h);
+            if (rc == CT_OK) {
+                rc = ensure_frames(h, S); // sized for the batches that follow, not for this short one
+            }
             S = std::min(S, kTuneSubframes);
             if (rc == CT_OK) {
                 rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
@@ -1111,20 +1229,25 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             const bool trace = getenv("CT_TRACE") != nullptr;
             const auto t0 = std::chrono::steady_clock::now();
             rc = prepare_batches(h, S);
+            if (rc == CT_OK && (size_t)S * frame_stride(h) > h->slot_capacity) {
+                rc = flush(h); // the scratch grows: nothing may be in flight
+                if (rc == CT_OK) {
+                    rc = ensure_frames(h, S);
+                }
+            }
             const auto t1 = std::chrono::steady_clock::now();
             if (wait) {
-                h->next_slot = 0; // synchronous batches never need the second slot (nor its scratch buffer)
+                rc = rc == CT_OK ? flush(h) : rc;
+                h->next_slot = 0; // synchronous batches use one slot and run every path to its end
             }
-            CtHandle_::Slot &sl = h->slots[h->next_slot];
+            const int slot = h->next_slot;
             if (rc == CT_OK) {
-                rc = collect(h, sl); // at most two batches in flight: wait for the one that used this slot
-            }
-            if (rc == CT_OK) {
-                rc = ensure_frames(h, sl, S);
+                rc = collect(h, h->slots[slot]); // book the launch that used this slot two batches ago
             }
             const auto t2 = std::chrono::steady_clock::now();
             if (rc == CT_OK) {
-                rc = submit_batch(h, sl, sl.frames, first_subframe_id + done, S, true);
+                const bool suspend = !wait && h->continuation && !simple && h->scene.estimator == CT_EST_MARCH;
+                rc = submit_batch(h, slot, nullptr, first_subframe_id + done, S, true, suspend);
             }
             if (trace) {
                 const auto t3 = std::chrono::steady_clock::now();
@@ -1217,7 +1340,7 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         HIPCHK(h, hipMemcpyAsync(d_jg, jg.data(), jg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(d_js, js.data(), js.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemsetAsync(d_cost, 0, n_groups * sizeof(uint32_t), h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_queue, 0, (kQueues + 1) * sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
         HIPCHK(h, launch_point_rays(h->dev, d_tasks, count, n_pad, d_primary, d_pixels, h->stream));
         BatchArgs ba{};
         ba.frames = d_frames;
@@ -1576,6 +1699,16 @@ extern "C" int ct_debug_stats(CtHandle h, uint64_t out[64])
     for (int i = 0; i < kStatCount; i++) {
         out[i] = c[i];
     }
+    return CT_OK;
+}
+
+extern "C" int ct_debug_suspended(CtHandle h, uint64_t *paths_out)
+{
+    NEED(h);
+    if (!paths_out) {
+        return fail(h, CT_E_INVAL, "paths_out is NULL");
+    }
+    *paths_out = h->suspended_total;
     return CT_OK;
 }
 

@@ -104,6 +104,7 @@ struct DevScene {
     uint32_t burst_scatter; // ... this many lanes wait for the scatter phase, or ...
     uint32_t burst_idle;   // ... this many lanes are idle)
     uint32_t tail_burst;   // march steps per visit once the job queue is empty
+    uint32_t hint_period;  // scheduler visits between two looks at the job counter (power of two, 0 = never)
     uint32_t burst_march_min; // a burst also ends when fewer lanes than this still march (>= 1)
     uint32_t scatter_num, scatter_den; // run the scatter phase when nb * den > nm * num ...
     uint32_t scatter_min;  // ... and at least this many lanes wait for it (or nobody marches)

@@ -11,6 +11,9 @@ namespace ct {
 constexpr int kTile = 8;            // pixel tile edge: 8x8 = one wave of primary rays
 constexpr int kCounterCount = 6;    // paths, box_hits, density, inscatter, scatter, capped
 constexpr int kStatCount = 64;      // scheduler diagnostics (ct_debug_stats)
+constexpr int kContWords = 16;      // words of a suspended path (render_persistent_kernel)
+constexpr int kQueueFlag = 32;       // word of the queue array (its own 128-B line) that says "job list empty"
+constexpr int kQueueWords = 64;      // size of a queue array
 constexpr int kQueues = 8;          // one job queue per XCD (MI355X: 8 XCDs, each with its own L2)
 
 // One progressive batch: subframes first .. first+S-1 of the handle's own tiles.
@@ -44,7 +47,19 @@ struct BatchArgs {
     uint32_t q_begin[kQueues + 2];
     uint32_t first_subframe;   // 1-based subframeId of slice 0
     uint32_t S;
-    uint32_t *queue;           // kQueues + 1 work counters, zero before launch
+    uint32_t *queue;           // kQueueWords words, zero before launch: kQueues + 1 work counters, the flag
+    // Path continuation (MARCH estimator, batches enqueued with ct_render_accumulate_async): when the job
+    // queue is empty a wave does not run its surviving paths to their end -- a launch would end with a
+    // tail of waves that carry a few long paths each, 19 ms of 107 at 256 subframes -- it writes their
+    // state (kContWords words each) to cont_out and exits; the next launch resumes them from cont_in
+    // before it takes jobs.  A resumed path is never suspended again and writes its result where it
+    // always would: out_offset selects the half of the scratch that belongs to its batch.
+    const uint32_t *cont_in;        // NULL: nothing to resume
+    const uint32_t *cont_in_count;  // entries in cont_in (device memory: written by the previous launch)
+    uint32_t *cont_cursor;          // zero before launch
+    uint32_t *cont_out;             // NULL: run every path to its end
+    uint32_t *cont_out_count;       // zero before launch
+    uint32_t out_offset;            // added to a compact result index (frame_stride != 0)
     unsigned long long *counters; // kCounterCount
     unsigned long long *stats;    // kStatCount
 };

@@ -596,6 +596,9 @@ CT_DEV bool take_job(const BatchArgs &ba, uint32_t lane, uint32_t &q_cur, uint32
             j = __builtin_amdgcn_readfirstlane(j);
             if (j < end - begin) {
                 job = begin + j;
+                if (job + 1u == ba.n_jobs && lane == 0) {
+                    __atomic_store_n(ba.queue + kQueueFlag, 1u, __ATOMIC_RELAXED); // see the suspend logic
+                }
                 return true;
             }
         }
@@ -698,9 +701,55 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0, st_iters = 0, st_first = 0;
 
+    // ---------------- resume the paths the previous launch suspended ----------------
+    bool resumed = false;   // this lane's path comes from cont_in: it is run to its end, never suspended again
+    if (ba.cont_in) {
+        const uint32_t total = __builtin_amdgcn_readfirstlane(*ba.cont_in_count);
+        uint32_t base = 0;
+        if (lane == 0) {
+            base = atomicAdd(ba.cont_cursor, 64u);
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + lane < total) {
+            const uint4 *e = (const uint4 *)(ba.cont_in + (size_t)(base + lane) * kContWords);
+            const uint4 w0 = e[0], w1 = e[1], w2 = e[2], w3 = e[3];
+            pos = mk3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
+            dir = mk3(__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y));
+            rad = mk3(__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x));
+            seed = w2.y;
+            out_idx = w2.z;
+            xi = __uint_as_float(w2.w);
+            T = __uint_as_float(w3.x);
+            inv_maxd = __uint_as_float(w3.y);
+            depth = w3.z & 0xffffu;
+            dfree = (w3.z >> 16) & 0xffu;
+            state = (int)(w3.z >> 24);
+            stepv = scale3(dir, sc.sample_step);
+            resumed = true;
+        }
+    }
+    const bool may_suspend = ba.cont_out != nullptr;
+    // one global list (queue 0 holds everything): a wave can see that it is empty without taking from it
+    const bool single_queue = ba.q_begin[1] == ba.n_jobs;
+
     const unsigned long long t_start = STATS ? wall_clock64() : 0ull; // 100 MHz
     unsigned long long t_drained = 0;
+    uint32_t visit = 0;
+    bool exhausted = false; // the job list is empty (seen through the flag or by failing to take a job)
     for (;;) {
+        visit += 1;
+        if (may_suspend && single_queue && !exhausted && sc.hint_period != 0u && (visit & (sc.hint_period - 1u)) == 0u) {
+            // is the job list empty?  (then this wave finishes its own job and suspends, below.)  The wave
+            // that takes the last job raises a flag in a cache line of its own: reading the job counter
+            // itself, the target of every wave's atomics, cost 10-30 % of the launch
+            const uint32_t empty = __builtin_amdgcn_readfirstlane(__atomic_load_n(ba.queue + kQueueFlag, __ATOMIC_RELAXED));
+            if (empty != 0u) {
+                exhausted = true;
+                if (q_next == q_end) {
+                    drained = true;
+                }
+            }
+        }
         if (STATS) {
             st_iters += 1;
             if (drained && t_drained == 0) {
@@ -745,7 +794,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                     if (pixel != 0xffffffffu) {
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                        out_idx = ba.frame_stride ? s * ba.frame_stride + (g * 64u + l) : pixel;
+                        out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + (g * 64u + l) : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f; // image jobs list hitting pixels only; point tasks may miss
@@ -754,6 +803,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                         rad = mk3(0, 0, 0);
                         depth = 0;
                         work = 0;
+                        resumed = false;
                         if (MODE == 1) {
                             dir = new_direction(lds.cdf, lds.guide, seed, dir);  // :86
                         }
@@ -946,6 +996,29 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 atomicMax(&ba.cost_max[group], depth);
             }
             state = ST_IDLE;
+        }
+        // ---------------- suspend: nothing left to take, hand the surviving paths to the next launch ----------------
+        // (also while this wave's own job still has samples left: its lanes are freed at once, the rest of
+        // the job starts in them and is suspended on the next visit)
+        if (may_suspend && (exhausted || drained)) {
+            const bool mine = state != ST_IDLE && !resumed;
+            const uint64_t live = __builtin_amdgcn_ballot_w64(mine);
+            if (live != 0ull) {
+                const uint32_t n = (uint32_t)__builtin_popcountll(live);
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(live)) {
+                    base = atomicAdd(ba.cont_out_count, n);
+                }
+                base = __builtin_amdgcn_readlane(base, __builtin_ctzll(live));
+                if (mine) {
+                    uint4 *e = (uint4 *)(ba.cont_out + (size_t)(base + lane_rank(live)) * kContWords);
+                    e[0] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), __float_as_uint(dir.x));
+                    e[1] = make_uint4(__float_as_uint(dir.y), __float_as_uint(dir.z), __float_as_uint(rad.x), __float_as_uint(rad.y));
+                    e[2] = make_uint4(__float_as_uint(rad.z), seed, out_idx, __float_as_uint(xi));
+                    e[3] = make_uint4(__float_as_uint(T), __float_as_uint(inv_maxd), depth | (dfree << 16) | ((uint32_t)state << 24), 0u);
+                    state = ST_IDLE;
+                }
+            }
         }
     }
 

@@ -53,6 +53,7 @@ class ShardedTracer:
         self.stage = world > 1 or stage_always       # stage_always: single-rank rehearsal of the staged path
         self.merged = torch.zeros((params.height, params.width, 4), dtype=torch.float32, device="cuda")
         self._nbytes = self.merged.numel() * 4
+        self._lagging = False
         self.stream = None
         if self.stage:
             torch.cuda.synchronize()                 # `merged` is zeroed before another stream touches it
@@ -81,18 +82,25 @@ class ShardedTracer:
         return None
 
     def step_async(self, first_subframe: int, count: int):
-        """The same without waiting: the batch is enqueued (two may be in flight, see
-        ct_render_accumulate_async); the copy of the running mean and the RCCL reduce are ordered behind
-        its accumulate kernel on the shared stream.  `merged` is valid on rank 0 after `synchronize()`."""
+        """The same without waiting: the batch is enqueued (ct_render_accumulate_async).  Its estimator
+        launch hands its surviving paths to the next one, so its accumulate kernel runs behind the NEXT
+        batch's launch: the running mean that this step copies and reduces is the one after the previous
+        batch.  `synchronize()` finishes the last batch and reduces once more; `merged` is complete on rank
+        0 after it."""
         self.tracer.render_accumulate_async(first_subframe, count)
         if self.stage:
             self.tracer.copy_to_device_async(_lib.CT_BUF_MEAN, self.merged.data_ptr(), self._nbytes)
             self._reduce()
+            self._lagging = True
             return self.merged
         return None
 
     def synchronize(self):
         self.tracer.synchronize()
+        if self.stage and self._lagging:
+            self.tracer.copy_to_device(_lib.CT_BUF_MEAN, self.merged.data_ptr(), self._nbytes)
+            self._reduce()
+            self._lagging = False
         if self.stream is not None:
             self.stream.synchronize()
 

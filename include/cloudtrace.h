@@ -183,13 +183,15 @@ CT_API int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *frame_rg
  * without materialising the frame buffer.  Requires first == (subframes accumulated so far)+1. */
 CT_API int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint32_t count);
 
-/* The same, pipelined: the call enqueues the batch and returns.  Up to two batches are in flight: the
- * estimator launch of batch k+1 runs on a second HIP stream while the last long paths of batch k finish
- * (a launch cannot be shorter than its deepest path), the accumulate kernels stay in subframe order on
- * the handle's stream (ct_set_stream), so results are identical to ct_render_accumulate's.  A third call
- * waits for the oldest batch.  Every other entry point waits for the batches in flight first, except
- * ct_copy_to_device_async, which is ordered on the handle's stream behind the accumulate kernels.
- * (The reference is synchronous: Camera::render maps its buffers right after context->launch,
+/* The same, pipelined: the call enqueues the batch on the handle's stream and returns.  With the MARCH
+ * estimator a launch does not run its surviving paths to their end once its job list is empty (that tail of
+ * waves carrying a few long paths each is 19 ms of a 107 ms launch at 256 subframes): it suspends them and the
+ * next batch's launch resumes them first, so the accumulate kernel of batch k runs behind the launch of batch
+ * k+1, and ct_synchronize() (or any entry point that waits) finishes the last batch with a launch that only
+ * resumes.  Paths, arithmetic and the subframe order of the accumulation are unchanged: results are identical
+ * to ct_render_accumulate's.  Every other entry point waits for the batches in flight first, except
+ * ct_copy_to_device_async and ct_subframes; a copy enqueued after batch k sees the running mean up to batch
+ * k-1.  (The reference is synchronous: Camera::render maps its buffers right after context->launch,
  * Camera.cpp:189-240; SURVEY section 8b asks for an _async variant.) */
 CT_API int ct_render_accumulate_async(CtHandle h, uint32_t first_subframe_id, uint32_t count);
 CT_API int ct_synchronize(CtHandle h);
@@ -293,6 +295,8 @@ CT_API int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_
  * scatter phases, scatter lanes, fetched march steps, fetched steps whose 8 texels were all 0,
  * skipped (replayed) march steps, skip-loop trips (wave level), rest reserved. */
 CT_API int ct_debug_stats(CtHandle h, uint64_t out[64]);
+/* Paths that ct_render_accumulate_async launches have handed to their successors so far (diagnostic). */
+CT_API int ct_debug_suspended(CtHandle h, uint64_t *paths_out);
 
 /* PMC calibration probe (no handle): allocates 2^log2_lines 128-byte lines on `device`, and has one
  * thread per line issue the estimator's access pattern (two unaligned 8-byte loads at byte 13 and

@@ -461,6 +461,38 @@ def test_pipelined_batches_equal_synchronous_batches():
     ref.close()
 
 
+def test_path_continuation_across_launches_is_bit_exact():
+    """Async batches of the MARCH estimator suspend their surviving paths when the job list is empty and the
+    next launch resumes them.  A thick medium (every path bounces for long) and small batches make sure that
+    thousands of paths cross launch boundaries; mean, M2 and the counters must equal the synchronous run's."""
+    tex = sphere_volume(48, radius=0.42, seed=17)
+    w, h = 256, 192
+    kw = dict(mode=0, cloud_size_m=30000.0, max_depth=300)
+    tr = ds.CloudTracer(tex, width=w, height=h, **kw)
+    ref = ds.CloudTracer(tex, width=w, height=h, **kw)
+    first = 1
+    for n in (4, 3, 5, 2, 6, 4):
+        tr.render_accumulate_async(first, n)
+        ref.render_accumulate(first, n)
+        first += n
+    tr.synchronize()
+    assert tr.debug_suspended() > 1000
+    assert np.array_equal(tr.mean(), ref.mean()) and np.array_equal(tr.m2(), ref.m2())
+    assert tr.counters() == ref.counters()
+    assert tr.counters()["depth_capped"] > 0
+    # and against the oracle on a window
+    orc = O.Oracle(tex, w, h, fast=True, **kw)
+    win = (96, 64, 160, 128)
+    mean, _ = orc.render(8, window=win)
+    tr2 = ds.CloudTracer(tex, width=w, height=h, **kw)
+    tr2.render_accumulate_async(1, 5)
+    tr2.render_accumulate_async(6, 3)
+    got = tr2.mean()
+    assert np.array_equal(got[win[1]:win[3], win[0]:win[2]], mean[win[1]:win[3], win[0]:win[2]])
+    for t in (tr, ref, tr2):
+        t.close()
+
+
 def test_sharded_tracer_staged_async_path_single_rank():
     """The multi-GPU step without a second GPU: the handle shares a torch stream, every step enqueues
     render + accumulate + the copy of the running mean into the staging tensor (the RCCL reduce is a

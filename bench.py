@@ -12,8 +12,9 @@ frame: estimator kernel + Welford accumulate kernel, plus (N>1) the reduce of th
 radiance buffer to rank 0.  The default run (4 steps) is exactly one 1024-spp image of
 BASELINE.json's configuration in four progressive updates.  (The reference updates its display
 every 10 subframes and saves every 40, Camera.cpp:189,211; a launch ends with a tail of waves that
-finish its long paths, 14.6 ms + 0.44 ms per spp measured, so the batch size trades update rate for
-throughput: 1510 Msamples/s at 64 spp per launch, 1880 at 128, 2030 at 256, 2080 at 512.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
+finish its long paths unless it may hand them to the next launch, which is what the enqueued steps of this
+benchmark do: 2280 Msamples/s at 64 spp per launch, 2540 at 128, 2680 at 256, 2770 at 512; waiting for every
+step: 1690, 2110, 2480, 2590.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
 before the timed region and resident in HBM).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -54,8 +55,8 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a box with one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="enqueue the steps (two launches in flight) instead of waiting for each one")
+    ap.add_argument("--sync-steps", action="store_true",
+                    help="wait for every step before the next one is enqueued (no path continuation across launches)")
     return ap.parse_args()
 
 
@@ -130,15 +131,16 @@ def main():
 
     def step(first):
         # estimator + accumulate on this rank's tiles, then (N>1) the RCCL SUM-reduce of the W*H float4
-        # radiance buffer to rank 0: tiles are disjoint, so the sum is an exact merge.  --pipelined enqueues
-        # the steps instead (ct_render_accumulate_async: the estimator launch of step k+1 starts on a
-        # second HIP stream while the last long paths of step k finish; accumulate, copy and reduce stay in
-        # order): +4 % at 128 spp per step, -3 % at 256, where two co-running launches disturb each other
-        # for longer than the tail they hide.
-        if args.pipelined:
-            st.step_async(first, S)
-        else:
+        # radiance buffer to rank 0: tiles are disjoint, so the sum is an exact merge.  Steps are enqueued
+        # (ct_render_accumulate_async): a launch hands its surviving paths to the next one instead of ending
+        # with a tail of waves that carry a few long paths each, so the accumulate kernel of step k (and, N>1,
+        # the copy + reduce of its running mean) runs behind the launch of step k+1 and the fence at the end
+        # finishes the last step with a launch that only resumes.  --sync-steps waits for every step instead
+        # (every launch then runs all of its paths to their end: 2480 instead of 2680 Msamples/s).
+        if args.sync_steps:
             st.step(first, S)
+        else:
+            st.step_async(first, S)
 
     def fence():
         st.synchronize()
@@ -169,7 +171,7 @@ def main():
         step(nxt)
         nxt += S
         step_marks.append(time.perf_counter() - t0)   # host time after the call (a waited-for step has finished)
-        if os.environ.get("CT_BENCH_VERBOSE") and not args.pipelined:
+        if os.environ.get("CT_BENCH_VERBOSE") and args.sync_steps:
             step_marks.append(tr.kernel_time()[0])
     fence()
     elapsed = time.perf_counter() - t0
@@ -237,7 +239,7 @@ def main():
                         f"{('MARCH (reference-faithful)', 'DELTA (Woodcock, brick majorants)')[args.estimator]}, max_depth 2000",
             "volume": args.volume, "width": W, "height": H, "spp_per_step": S,
             "parallelism": f"pixel-tile shard x{world}" + (" + RCCL reduce of the radiance buffer" if world > 1 else ""),
-            "pipelined_steps": bool(args.pipelined),
+            "pipelined_steps": not args.sync_steps,
         },
         "roofline": roofline,
         "setup_s": setup_s,

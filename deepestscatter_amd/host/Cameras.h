@@ -119,6 +119,7 @@ namespace DeepestScatter
         uint32_t subframesPerUpdate = 10;
         uint32_t maxSubframes = 0;      // 0 = until isConverged()
         bool fused = true;              // one ct_render_accumulate per update instead of 2 launches per subframe
+        bool headless = false;          // no display: enqueue the batches, read the buffers only where the reference saves
         bool completed = true;          // Camera.h:55
 
         uint32_t getSubframeId() const { return subframeId; }
@@ -160,7 +161,11 @@ namespace DeepestScatter
 
         void render()                                                            // :177-230
         {
-            if (!isConverged() && !(maxSubframes && subframeId >= maxSubframes))
+            // headless: nobody looks at the screen between saves, so batches are enqueued (a launch hands its
+            // unfinished paths to the next one instead of ending with a tail) and the buffers are only read --
+            // convergence test, tonemap, save -- every 40 subframes, where the reference saves (:211-214)
+            const bool look = !headless || subframeId % 40 == 0;
+            if (!(look && isConverged()) && !(maxSubframes && subframeId >= maxSubframes))
             {
                 uint32_t count = subframesPerUpdate;
                 if (maxSubframes) count = std::min(count, maxSubframes - subframeId);
@@ -174,7 +179,10 @@ namespace DeepestScatter
                                        context->handle, "ct_set_camera");
                         camera->valid = false;
                     }
-                    Context::check(ct_render_accumulate(context->handle, subframeId + 1, count), context->handle, "ct_render_accumulate");
+                    if (headless)
+                        Context::check(ct_render_accumulate_async(context->handle, subframeId + 1, count), context->handle, "ct_render_accumulate_async");
+                    else
+                        Context::check(ct_render_accumulate(context->handle, subframeId + 1, count), context->handle, "ct_render_accumulate");
                     subframeId += count;
                     std::cout << "rendering subframe " << subframeId << std::endl;
                 }
@@ -189,8 +197,11 @@ namespace DeepestScatter
                         Context::check(ct_accumulate(context->handle, subframeId, nullptr), context->handle, "ct_accumulate");   // :197-199
                     }
                 }
-                screen.resize((size_t)width * height * 4);
-                Context::check(ct_tonemap(context->handle, exposure, screen.data(), nullptr), context->handle, "ct_tonemap");   // :202-210
+                if (!headless || subframeId % 40 == 0)
+                {
+                    screen.resize((size_t)width * height * 4);
+                    Context::check(ct_tonemap(context->handle, exposure, screen.data(), nullptr), context->handle, "ct_tonemap");   // :202-210
+                }
                 if (subframeId % 40 == 0) saveToDisk();                           // :211-214
             }
             else

@@ -4,7 +4,7 @@
 // (GuiExecutionLoop.cpp:85-128) becomes a plain while(!scene->isCompleted()) scene->update().
 //
 //   cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light Side|Back|Front]
-//              [--size-m 7000] [--out DIR] [--data DIR] [--unfused] [--format exr|pfm]
+//              [--size-m 7000] [--out DIR] [--data DIR] [--unfused] [--display] [--format exr|pfm]
 //   <cloud> = procedural:<N>[:<seed>] | file.f32grid
 #include <chrono>
 #include <cstring>
@@ -45,6 +45,7 @@ namespace
         float sizeM = 7000.f;                                                     // main.cpp:63
         std::string outDir = ".", dataDir, format = "exr";
         bool fused = true;
+        bool display = false;                                                     // --display: tonemap + convergence test after every update, like the GUI
     };
 
     using LazyTask = std::function<std::shared_ptr<Scene>()>;
@@ -73,6 +74,7 @@ namespace
             camera->completed = false;                                            // Tasks.cpp:97-98
             camera->maxSubframes = opt.spp;
             camera->fused = opt.fused;
+            camera->headless = opt.fused && !opt.display;
             std::vector<std::shared_ptr<SceneItem>> items{ sun, cloud, material, camera };
             return std::make_shared<Scene>(items, context, opt.dataDir);
         };
@@ -84,7 +86,7 @@ int main(int argc, char* argv[])
     try
     {
         Options opt;
-        if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused] [--format exr|pfm]\n"; return 2; }
+        if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused] [--display] [--format exr|pfm]\n"; return 2; }
         opt.cloud = argv[1];
         opt.dataDir = (std::filesystem::path(argv[0]).parent_path() / ".." / "data").string();
         for (int i = 2; i < argc; i++)
@@ -97,6 +99,7 @@ int main(int argc, char* argv[])
             else if (a == "--out") opt.outDir = next();
             else if (a == "--data") opt.dataDir = next();
             else if (a == "--unfused") opt.fused = false;
+            else if (a == "--display") opt.display = true;
             else if (a == "--format") { opt.format = next(); if (opt.format != "exr" && opt.format != "pfm") throw std::invalid_argument("--format exr|pfm"); }
             else if (a == "--mode")
             {

@@ -992,6 +992,7 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     if (suspend) {
         ba.cont_out = sl.cont;
         ba.cont_out_count = h->d_cont_count + slot;
+        ba.cont_capacity = (uint32_t)h->cont_capacity;
         HIPCHK(h, hipMemsetAsync(h->d_cont_count + slot, 0, sizeof(uint32_t), h->stream));
     }
     HIPCHK(h, hipMemsetAsync(sl.queue, 0, kQueueWords * sizeof(uint32_t), h->stream));

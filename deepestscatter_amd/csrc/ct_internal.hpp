@@ -59,6 +59,7 @@ struct BatchArgs {
     uint32_t *cont_cursor;          // zero before launch
     uint32_t *cont_out;             // NULL: run every path to its end
     uint32_t *cont_out_count;       // zero before launch
+    uint32_t cont_capacity;         // entries cont_out can hold
     uint32_t out_offset;            // added to a compact result index (frame_stride != 0)
     unsigned long long *counters; // kCounterCount
     unsigned long long *stats;    // kStatCount

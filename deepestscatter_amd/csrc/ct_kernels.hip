@@ -1008,9 +1008,13 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 uint32_t base = 0;
                 if (lane == (uint32_t)__builtin_ctzll(live)) {
                     base = atomicAdd(ba.cont_out_count, n);
+                    if (base + n > ba.cont_capacity) {
+                        atomicSub(ba.cont_out_count, n); // no room (cannot happen with the host's sizing): keep running
+                        base = 0xffffffffu;
+                    }
                 }
                 base = __builtin_amdgcn_readlane(base, __builtin_ctzll(live));
-                if (mine) {
+                if (mine && base != 0xffffffffu) {
                     uint4 *e = (uint4 *)(ba.cont_out + (size_t)(base + lane_rank(live)) * kContWords);
                     e[0] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), __float_as_uint(dir.x));
                     e[1] = make_uint4(__float_as_uint(dir.y), __float_as_uint(dir.z), __float_as_uint(rad.x), __float_as_uint(rad.y));

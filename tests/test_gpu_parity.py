@@ -170,6 +170,25 @@ def test_march_bricks_on_adversarial_volumes(dims):
     tr.close()
 
 
+@pytest.mark.parametrize("dims", [(2, 2, 2), (3, 5, 4), (4, 3, 9), (7, 8, 5)])
+def test_tiny_random_volumes_without_zero_border(dims):
+    """Smallest legal volumes, every texel random (no zero border, so the march ends by isInBox alone) and
+    fewer texels than a brick on some axis.  1x1x1 is refused like any dimension below 2."""
+    rng = np.random.default_rng(sum(dims))
+    tex = rng.integers(0, 256, dims[::-1]).astype(np.uint8)
+    tr, orc = make_pair(tex, 24, 16, mode=0, cloud_size_m=50.0)
+    tr.render_accumulate_async(1, 3)
+    tr.render_accumulate_async(4, 2)
+    mean, m2 = orc.render(5)
+    assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2)
+    assert tr.counters() == orc.counters.as_dict()
+    assert np.array_equal(tr.inscatter(), orc.inscatter)
+    tr.close()
+    with pytest.raises(_lib.CloudTraceError) as e:
+        ds.CloudTracer(np.zeros((1, 1, 1), np.uint8), width=8, height=8)
+    assert e.value.code == _lib.CT_E_INVAL
+
+
 def test_simple_kernel_equals_persistent_kernel():
     tex = sphere_volume(32, seed=6)
     a = ds.CloudTracer(tex, width=40, height=32, mode=0)

@@ -2,14 +2,31 @@
 //
 //   render_persistent_kernel   the estimator (cloudRadianceMaterials.cu:9-148 + cloud.cuh:77-188 +
 //                              pathTracingCamera.cu:12-21 + cloudBBox.cu:7-37) as a persistent,
-//                              wave-scheduled state machine with path regeneration
-//   render_simple_kernel       the same estimator, one thread per pixel, nested loops (A/B and
-//                              cross-check only)
-//   accumulate_batch_kernel    updateFrameResult (progressive.cu:17-27) over S subframes in order
+//                              wave-scheduled state machine: path regeneration from a job queue, march
+//                              bursts / scatter phases, exact free-space skipping, suspension of the
+//                              surviving paths at the end of a launch and their resumption by the next
+//   render_delta_kernel        the same scheduler around Woodcock tracking over brick majorants (DELTA)
+//   render_simple_kernel       the MARCH estimator, one thread per pixel, nested loops (A/B and cross-check)
+//   primary_rays_kernel, primary_advance_kernel, primary_advance_delta_kernel
+//                              per pose: primary ray per pixel and the part of its flight that is the same
+//                              for every sample of the pixel
+//   accumulate_batch_kernel, accumulate_list_kernel, accumulate_miss_kernel
+//                              updateFrameResult (progressive.cu:17-27) over S subframes in order
 //   inscatter_kernel           inScatter.cu:40-66
-//   build_bricks_kernel        uint8 volume -> 128-byte apron bricks (replaces the texture unit)
+//   build_bricks_kernel, brick_free_kernel, brick_dist_relax_kernel, brick_meta_kernel
+//                              uint8 volume -> 128-byte apron bricks of 4^3 texels + meta bytes
+//   blocked_mask_kernel, cheb_pass_kernel, build_mbricks_kernel
+//                              texel-granular clearance (capped Chebyshev distance transform) and the
+//                              3x4x4 march bricks with a meta byte per row
+//   point_rays_kernel, point_accumulate_kernel, scatter_samples_kernel
+//                              the dataset collectors' device parts (pointEmissionCamera.cu,
+//                              PointRadianceTask.h, pointGeneratorCamera.cu, cloudFirstScatterMaterial.cu)
+//   mip_level_kernel, descriptor_kernel
+//                              Resources::generateMipmaps + setupHierarchicalDescriptor (DisneyDescriptor.cuh)
 //   reinhard_*                 reinhard.cu:26-84
 //   converged_kernel           Camera::isConverged (Camera.cpp:232-268)
+//   cdf_selftest_kernel, fetch_probe_kernel
+//                              diagnostics (exhaustive CDF inversion test, FETCH_SIZE calibration)
 //
 // Compile with -ffp-contract=off: results must be bit-identical to oracle/ct_oracle.c.
 #include <algorithm>

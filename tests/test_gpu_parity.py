@@ -512,6 +512,29 @@ def test_path_continuation_across_launches_is_bit_exact():
         t.close()
 
 
+def test_shards_with_enqueued_batches_sum_to_the_whole():
+    """Pixel-tile shards (one handle per GPU in production) rendered with enqueued batches and path
+    continuation merge into the unsharded image bit for bit."""
+    tex = sphere_volume(40, radius=0.4, seed=23)
+    w, h = 120, 88
+    kw = dict(mode=0, cloud_size_m=20000.0, max_depth=400)
+    whole = ds.CloudTracer(tex, width=w, height=h, **kw)
+    whole.render_accumulate(1, 9)
+    merged = np.zeros_like(whole.mean())
+    paths = 0
+    for i in range(3):
+        sh = ds.CloudTracer(tex, width=w, height=h, shard_index=i, shard_count=3, **kw)
+        sh.render_accumulate_async(1, 4)
+        sh.render_accumulate_async(5, 3)
+        sh.render_accumulate_async(8, 2)
+        merged += sh.mean()
+        paths += sh.counters()["paths"]
+        sh.close()
+    assert np.array_equal(merged, whole.mean())
+    assert paths == whole.counters()["paths"]
+    whole.close()
+
+
 def test_sharded_tracer_staged_async_path_single_rank():
     """The multi-GPU step without a second GPU: the handle shares a torch stream, every step enqueues
     render + accumulate + the copy of the running mean into the staging tensor (the RCCL reduce is a

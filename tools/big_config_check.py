@@ -9,3 +9,5 @@ t=time.time(); tr.render_accumulate(5,32); dt=time.time()-t; print('32 spp', dt,
 c=tr.counters(); print(c, 'lookups/sample', (c['density_lookups']+c['inscatter_lookups'])/c['paths'])
 m=tr.mean(); print('finite', np.isfinite(m).all(), 'mean radiance', m[...,0].mean(), 'max', m[...,0].max())
 print(tr.kernel_time())
+t=time.time(); tr.render_accumulate_async(37,64); tr.render_accumulate_async(101,64); tr.synchronize(); dt=time.time()-t; print('2 x 64 spp enqueued', dt, 'Msamples/s', 2048*2048*128/dt/1e6, 'suspended', tr.debug_suspended())
+m2=tr.mean(); print('finite', np.isfinite(m2).all(), 'mean radiance', m2[...,0].mean())

@@ -1055,9 +1055,9 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
         vals[i] = v;
     }
     if (STATS) {
-        uint32_t sv[6] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1, st_skip_iters };
+        uint32_t sv[7] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1, st_skip_iters, st_first };
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < 7; i++) {
             uint32_t v = sv[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -1078,14 +1078,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             atomicAdd(&ba.stats[9], (unsigned long long)sv[3]);
             atomicAdd(&ba.stats[10], (unsigned long long)sv[4]);
             atomicAdd(&ba.stats[11], (unsigned long long)sv[5]);
-            {
-                uint32_t v = st_first;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    v += __shfl_xor(v, off);
-                }
-                atomicAdd(&ba.stats[12], (unsigned long long)v);
-            }
+            atomicAdd(&ba.stats[12], (unsigned long long)sv[6]);
             atomicAdd(&ba.stats[13], 1ull);
             atomicAdd(&ba.stats[14], (unsigned long long)st_stolen);
             atomicMax(&ba.stats[15], (unsigned long long)st_iters);

@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArg
                     if (pixel != 0xffffffffu) {
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                        out_idx = ba.frame_stride ? s * ba.frame_stride + (g * 64u + l) : pixel;
+                        out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + (g * 64u + l) : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f;

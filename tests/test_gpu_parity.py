@@ -705,3 +705,63 @@ def test_north_star_parity_after_1024_spp_on_a_window():
     assert np.array_equal(got, ref)
     assert np.array_equal(m2[y0:y0 + 16, x0:x0 + 16], ref_m2[y0:y0 + 16, x0:x0 + 16])
     tr.close()
+
+
+def _random_scene(rng):
+    dims = tuple(int(v) for v in rng.integers(5, 41, 3))
+    nz, ny, nx = dims[::-1]
+    kind = int(rng.integers(0, 4))
+    if kind == 0:                                         # blobs
+        t = np.zeros((nz, ny, nx), np.float32)
+        z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        for _ in range(int(rng.integers(1, 5))):
+            c = rng.uniform(0.2, 0.8, 3) * (nz, ny, nx)
+            r = rng.uniform(0.1, 0.35) * min(dims)
+            t += np.clip(1.0 - np.sqrt((z - c[0]) ** 2 + (y - c[1]) ** 2 + (x - c[2]) ** 2) / r, 0, 1)
+        tex = (np.clip(t, 0, 1) * 255).astype(np.uint8)
+    elif kind == 1:                                       # sparse specks
+        tex = np.where(rng.random((nz, ny, nx)) < rng.uniform(0.002, 0.05), rng.integers(1, 256, (nz, ny, nx)), 0).astype(np.uint8)
+    elif kind == 2:                                       # dense noise, no border
+        tex = rng.integers(0, 256, (nz, ny, nx)).astype(np.uint8)
+    else:                                                 # slabs and holes
+        tex = np.zeros((nz, ny, nx), np.uint8)
+        tex[:, :, nx // 3: 2 * nx // 3] = rng.integers(20, 255)
+        tex[nz // 4: nz // 2, ny // 4: ny // 2, :] = 0
+    if kind != 2 and rng.random() < 0.7:                  # the reference's zero border
+        tex[0], tex[-1], tex[:, 0], tex[:, -1], tex[:, :, 0], tex[:, :, -1] = 0, 0, 0, 0, 0, 0
+    light = rng.normal(size=3)
+    eye = rng.normal(size=3)
+    eye = eye / np.linalg.norm(eye) * rng.uniform(0.3, 3.0)    # inside the box now and then
+    return dict(tex=tex, width=int(rng.integers(9, 49)), height=int(rng.integers(9, 41)),
+                mode=int(rng.integers(0, 3)), estimator=int(rng.random() < 0.3),
+                cloud_size_m=float(rng.choice([80.0, 700.0, 7000.0, 40000.0])),
+                sample_step=float(rng.choice([1 / 512, 1 / 256, 1 / 100])),
+                max_depth=int(rng.choice([2, 17, 300, 2000])), light_direction=tuple(float(v) for v in light)), tuple(float(v) for v in eye)
+
+
+def test_randomized_differential_against_the_oracle():
+    """Random volumes (blobs, specks, dense noise without a border, slabs with holes), frame sizes, modes,
+    estimators, step sizes, depth caps, lights and eyes (inside the box too), rendered with a random mix of
+    synchronous and enqueued batches: radiance, M2 and every counter must equal the oracle's."""
+    rng = np.random.default_rng(20261003)
+    for case in range(24):
+        kw, eye = _random_scene(rng)
+        tex = kw.pop("tex")
+        w, h = kw.pop("width"), kw.pop("height")
+        tr, orc = make_pair(tex, w, h, **kw)
+        U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
+        tr.set_camera(eye, U, V, W)
+        orc.set_camera(eye, U, V, W)
+        first = 1
+        for n in rng.integers(1, 5, 4):
+            if rng.random() < 0.6:
+                tr.render_accumulate_async(first, int(n))
+            else:
+                tr.render_accumulate(first, int(n))
+            first += int(n)
+        mean, m2 = orc.render(first - 1)
+        tag = f"case {case}: dims {tex.shape[::-1]} {w}x{h} {kw} eye {eye}"
+        assert np.array_equal(tr.mean(), mean), tag
+        assert np.array_equal(tr.m2(), m2), tag
+        assert tr.counters() == orc.counters.as_dict(), tag
+        tr.close()

@@ -500,9 +500,8 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, dmalloc(&h->d_queue, kQueueWords));
     HIPCHK(h, dmalloc(&h->d_cont_count, 3));
     HIPCHK(h, hipMemsetAsync(h->d_cont_count, 0, 3 * sizeof(uint32_t), h->stream));
-    // a lane suspends the path it carries when the job list runs empty, and once more per sample that is left
-    // in its wave's last job (at most 8 x 64 samples spread over 64 lanes)
-    h->cont_capacity = (size_t)h->shape.blocks * h->shape.threads * 10;
+    // a lane suspends at most one path per launch, and a launch resumes up to 64 paths per wave: the same number
+    h->cont_capacity = (size_t)h->shape.blocks * h->shape.threads;
     HIPCHK(h, hipEventCreate(&h->ev_flush0));
     HIPCHK(h, hipEventCreate(&h->ev_flush1));
     if (const char *e = getenv("CT_CONTINUATION")) {

@@ -752,19 +752,15 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
     const unsigned long long t_start = STATS ? wall_clock64() : 0ull; // 100 MHz
     unsigned long long t_drained = 0;
     uint32_t visit = 0;
-    bool exhausted = false; // the job list is empty (seen through the flag or by failing to take a job)
     for (;;) {
         visit += 1;
-        if (may_suspend && single_queue && !exhausted && sc.hint_period != 0u && (visit & (sc.hint_period - 1u)) == 0u) {
+        if (may_suspend && single_queue && !drained && sc.hint_period != 0u && (visit & (sc.hint_period - 1u)) == 0u) {
             // is the job list empty?  (then this wave finishes its own job and suspends, below.)  The wave
             // that takes the last job raises a flag in a cache line of its own: reading the job counter
             // itself, the target of every wave's atomics, cost 10-30 % of the launch
             const uint32_t empty = __builtin_amdgcn_readfirstlane(__atomic_load_n(ba.queue + kQueueFlag, __ATOMIC_RELAXED));
-            if (empty != 0u) {
-                exhausted = true;
-                if (q_next == q_end) {
-                    drained = true;
-                }
+            if (empty != 0u && q_next == q_end) {
+                drained = true;
             }
         }
         if (STATS) {
@@ -1015,9 +1011,9 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
             state = ST_IDLE;
         }
         // ---------------- suspend: nothing left to take, hand the surviving paths to the next launch ----------------
-        // (also while this wave's own job still has samples left: its lanes are freed at once, the rest of
-        // the job starts in them and is suspended on the next visit)
-        if (may_suspend && (exhausted || drained)) {
+        // (only once this wave's own job is used up: a lane then suspends at most one path per launch, which
+        // is what the next launch can resume -- 64 paths per wave -- and what cont_out is sized for)
+        if (may_suspend && drained && q_next == q_end) {
             const bool mine = state != ST_IDLE && !resumed;
             const uint64_t live = __builtin_amdgcn_ballot_w64(mine);
             if (live != 0ull) {

@@ -765,3 +765,38 @@ def test_randomized_differential_against_the_oracle():
         assert np.array_equal(tr.m2(), m2), tag
         assert tr.counters() == orc.counters.as_dict(), tag
         tr.close()
+
+
+def test_randomized_continuation_soak():
+    """Random scenes at frame sizes where tens of thousands of paths cross launch boundaries: enqueued batches
+    (with an occasional synchronize in between) against synchronous ones on the HIP path -- mean, M2 and every
+    counter bit for bit.  (tools/soak_continuation.py runs hundreds of these; an early version that let a lane
+    suspend several paths per launch lost samples in 4 cases of 150 and was found this way.)"""
+    rng = np.random.default_rng(77)
+    suspended = 0
+    for case in range(12):
+        kw, eye = _random_scene(rng)
+        tex = kw.pop("tex")
+        kw.pop("width"), kw.pop("height")
+        w, h = int(rng.integers(96, 320)), int(rng.integers(64, 256))
+        kw.update(estimator=0, sample_step=1.0 / 512, cloud_size_m=float(rng.choice([7000.0, 20000.0, 40000.0])),
+                  max_depth=int(rng.choice([50, 300, 2000])))
+        a = ds.CloudTracer(tex, width=w, height=h, **kw)
+        b = ds.CloudTracer(tex, width=w, height=h, **kw)
+        U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
+        a.set_camera(eye, U, V, W)
+        b.set_camera(eye, U, V, W)
+        first = 1
+        for n in rng.integers(1, 9, int(rng.integers(2, 7))):
+            a.render_accumulate_async(first, int(n))
+            b.render_accumulate(first, int(n))
+            first += int(n)
+            if rng.random() < 0.2:
+                a.synchronize()
+        tag = f"case {case}: dims {tex.shape[::-1]} {w}x{h} {kw} eye {eye}"
+        assert np.array_equal(a.mean(), b.mean()) and np.array_equal(a.m2(), b.m2()), tag
+        assert a.counters() == b.counters(), tag
+        suspended += a.debug_suspended()
+        a.close()
+        b.close()
+    assert suspended > 100000

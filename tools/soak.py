@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Soak run of the randomized differential test's generator: many random scenes and batch patterns, HIP path
+vs oracle, bit for bit.  python tools/soak.py <seed> <cases>"""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import torch  # noqa: F401  (first: see tests/conftest.py)
+import numpy as np
+import deepestscatter_amd as ds
+from test_gpu_parity import _random_scene, make_pair
+
+seed, cases = int(sys.argv[1]), int(sys.argv[2])
+rng = np.random.default_rng(seed)
+bad = 0
+for case in range(cases):
+    kw, eye = _random_scene(rng)
+    tex = kw.pop("tex"); w, h = kw.pop("width"), kw.pop("height")
+    tr, orc = make_pair(tex, w, h, **kw)
+    U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
+    tr.set_camera(eye, U, V, W); orc.set_camera(eye, U, V, W)
+    first = 1
+    pattern = []
+    for n in rng.integers(1, 5, 4):
+        a = bool(rng.random() < 0.6)
+        (tr.render_accumulate_async if a else tr.render_accumulate)(first, int(n))
+        pattern.append((int(n), a)); first += int(n)
+    mean, m2 = orc.render(first - 1)
+    ok = np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2) and tr.counters() == orc.counters.as_dict()
+    if not ok:
+        bad += 1
+        print(f"MISMATCH seed {seed} case {case}: dims {tex.shape[::-1]} {w}x{h} {kw} eye {eye} batches {pattern}", flush=True)
+    tr.close()
+    if case % 50 == 49:
+        print(f"{case + 1} cases, {bad} mismatches", flush=True)
+print(f"done: {cases} cases, {bad} mismatches")

@@ -800,3 +800,40 @@ def test_randomized_continuation_soak():
         a.close()
         b.close()
     assert suspended > 100000
+
+
+def test_scheduler_knobs_never_change_a_result(monkeypatch):
+    """Every CT_* knob only changes the schedule (burst lengths, regeneration and scatter thresholds, per-XCD
+    queues, blocks per CU, the pre-walked prefix, path continuation, the queue-empty hint): mean, M2 and the
+    counters of enqueued batches must be identical under any of them."""
+    tex = sphere_volume(44, radius=0.38, seed=41)
+    w, h = 200, 144
+    kw = dict(mode=0, cloud_size_m=20000.0, max_depth=500)
+
+    def run():
+        tr = ds.CloudTracer(tex, width=w, height=h, **kw)
+        tr.render_accumulate_async(1, 5)
+        tr.render_accumulate_async(6, 3)
+        tr.render_accumulate_async(9, 6)
+        out = (tr.mean(), tr.m2(), tr.counters())
+        tr.close()
+        return out
+
+    base = run()
+    settings = [
+        {"CT_MARCH_BURST": "1"}, {"CT_MARCH_BURST": "3", "CT_BURST_SCATTER": "5", "CT_BURST_IDLE": "7"},
+        {"CT_MARCH_BURST": "64", "CT_BURST_SCATTER": "65", "CT_BURST_IDLE": "65"},
+        {"CT_REGEN_MIN": "1"}, {"CT_REGEN_MIN": "64"}, {"CT_SCATTER_MIN": "20"}, {"CT_SCATTER_RATIO": "1/2"},
+        {"CT_XCD_QUEUES": "1"}, {"CT_XCD_QUEUES": "1", "CT_XCD_REGIONS": "8", "CT_SHARED_DEPTH": "4"},
+        {"CT_BLOCKS_PER_CU": "1"}, {"CT_BLOCKS_PER_CU": "3"},
+        {"CT_NO_ADVANCE": "1"}, {"CT_CONTINUATION": "0"}, {"CT_HINT_PERIOD": "1"}, {"CT_HINT_PERIOD": "0"},
+        {"CT_TAIL_BURST": "1"}, {"CT_BURST_MARCH_MIN": "20"},
+    ]
+    for env in settings:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
+        assert got[2] == base[2], env

@@ -837,3 +837,14 @@ def test_scheduler_knobs_never_change_a_result(monkeypatch):
             monkeypatch.delenv(k)
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
         assert got[2] == base[2], env
+
+
+def test_multi_gpu_step_on_the_rccl_backend_single_rank():
+    """tools/nccl_single_rank_check.py in a child process: the enqueued multi-GPU step (accumulate, copy of the
+    running mean, dist.reduce on the shared torch stream) with backend "nccl" = RCCL, world size 1."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parents[1] / "tools" / "nccl_single_rank_check.py"
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NCCL single-rank check: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

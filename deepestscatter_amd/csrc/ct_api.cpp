@@ -286,7 +286,7 @@ static int create_impl(const CtScene *s, CtHandle h)
     for (auto &e : h->ev) {
         HIPCHK(h, hipEventCreate(&e));
     }
-    h->shape = persistent_shape(s->device);
+    h->shape = persistent_shape(s->device, s->estimator == CT_EST_DELTA);
 
     // ---- uniforms: VDBCloud::setupVolumeVariables (VDBCloud.cpp:98-111), Sun::init (Sun.cpp:13-18)
     DevScene &d = h->dev;

@@ -137,6 +137,6 @@ hipError_t launch_mip_level(const uint8_t *prev, int px, int py, int pz, uint8_t
 hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const float *positions, const float *directions,
                               uint32_t count, float level0, float voxel_m, float cloud_size_m, uint8_t *out,
                               hipStream_t stream);
-LaunchShape persistent_shape(int device);
+LaunchShape persistent_shape(int device, bool delta);
 
 } // namespace ct

@@ -367,6 +367,27 @@ struct MieLds {
     uint16_t guide[kGuideN + 2];
 };
 
+// The MARCH kernel also keeps the chopped phase table there (NEE reads two neighbouring entries of it at
+// every bounce but the first): 40 KiB per block, which 512-thread blocks make affordable (3 per CU, the
+// same 6 waves per SIMD) -- one divergent gather per scatter less on an L1 that is busy 77 % of all cycles.
+struct MieLdsFull {
+    float cdf[kMieN];
+    float chopped[kMieN];
+    uint16_t guide[kGuideN + 2];
+};
+
+CT_DEV void load_tables(const DevScene &sc, MieLdsFull &lds)
+{
+    for (int i = threadIdx.x; i < kMieN; i += blockDim.x) {
+        lds.cdf[i] = sc.cdf[i];
+        lds.chopped[i] = sc.chopped[i];
+    }
+    for (int i = threadIdx.x; i < kGuideN + 2; i += blockDim.x) {
+        lds.guide[i] = sc.guide[i];
+    }
+    __syncthreads();
+}
+
 CT_DEV void load_tables(const DevScene &sc, MieLds &lds)
 {
     for (int i = threadIdx.x; i < kMieN; i += blockDim.x) {
@@ -550,6 +571,29 @@ CT_DEV NeeLoads in_scattering_issue(const DevScene &sc, f3 pos, f3 dir, bool cho
     return n;
 }
 
+// The same with the chopped table in LDS (MARCH kernel); the un-chopped one (first bounce) stays global.
+CT_DEV NeeLoads in_scattering_issue_lds(const DevScene &sc, const float *lds_chopped, f3 pos, f3 dir, bool chopped)
+{
+    NeeLoads n;
+    const float cos_light = dot3(mk3(sc.nlx, sc.nly, sc.nlz), dir);
+    const float u = (cos_light + 1) / 2;
+    const float x = fmaf(u, (float)kMieN, -0.5f);
+    const int32_t i = (int32_t)floorf(x);
+    const int32_t j = min(max(i, 0), kMieN - 2);
+    float2 pair;
+    if (chopped) {
+        pair = make_float2(lds_chopped[j], lds_chopped[j + 1]);
+    } else {
+        __builtin_memcpy(&pair, sc.mie + j, sizeof pair);
+    }
+    n.a = (i > kMieN - 2) ? pair.y : pair.x;
+    n.b = (i < 0) ? pair.x : pair.y;
+    n.w = fract_(x);
+    uint32_t meta_unused;
+    n.cell = fetch_cell(sc, sc.ibricks, pos, meta_unused);
+    return n;
+}
+
 CT_DEV f3 in_scattering_finish(const DevScene &sc, const NeeLoads &n, f3 pos)
 {
     const float phase = fmaf(n.w, n.b - n.a, n.a);
@@ -695,9 +739,9 @@ hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, flo
 // The queue hands out jobs = (pixel group, subframe range); a group is 64 consecutive entries of
 // the list of this shard's box-hitting pixels (tile-Morton order).  See BatchArgs for the order.
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, BatchArgs ba)
+__global__ __launch_bounds__(512) void render_persistent_kernel(DevScene sc, BatchArgs ba)
 {
-    __shared__ MieLds lds;
+    __shared__ MieLdsFull lds;
     load_tables(sc, lds);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -881,7 +925,7 @@ __global__ __launch_bounds__(256) void render_persistent_kernel(DevScene sc, Bat
                 // isInBox(scatterPos), cloudRadianceMaterials.cu:49-52
                 if (dfree != 0u || in_box(sc, pos)) {
                     const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
-                    const NeeLoads nee = in_scattering_issue(sc, pos, dir, chopped);
+                    const NeeLoads nee = in_scattering_issue_lds(sc, lds.chopped, pos, dir, chopped);
                     c_il += 1;
                     work += 4u;
                     bool go = (MODE != 2);
@@ -1618,16 +1662,18 @@ hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchSh
     return hipGetLastError();
 }
 
-LaunchShape persistent_shape(int device)
+LaunchShape persistent_shape(int device, bool delta)
 {
     hipDeviceProp_t prop;
-    LaunchShape s{ 1024, 256 };
+    LaunchShape s{ 1024, delta ? 256 : 512 };
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
-        // as many 256-thread blocks per CU as the kernel's registers and LDS (24 KiB) admit
+        // as many blocks per CU as the kernel's registers and LDS admit: MARCH 512 threads / 40 KiB,
+        // DELTA 256 threads / 24 KiB
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_persistent_kernel<0, false>, 256, 0) != hipSuccess ||
-            per_cu < 1) {
-            per_cu = 6;
+        const hipError_t e = delta ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_delta_kernel<0, false>, 256, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_persistent_kernel<0, false>, 512, 0);
+        if (e != hipSuccess || per_cu < 1) {
+            per_cu = delta ? 5 : 3;
         }
         s.blocks = prop.multiProcessorCount * std::min(per_cu, 8);
         if (const char *e = getenv("CT_BLOCKS_PER_CU")) {   // tuning knob for experiments

@@ -346,6 +346,11 @@ static int create_impl(const CtScene *s, CtHandle h)
     // the speed (the kernel is bound by the L1 gather rate and by instruction issue, not by L2
     // misses), and any imbalance between regions costs more than that: off unless asked for
     h->queues_enabled = false;
+    // ... unless the volume is far larger than the caches: at 1024^3 (2.7 GB of march bricks) the regional
+    // queues are worth +4.5 % (1824 -> 1906 Msamples/s at 2048^2); at 512^3 they cost 0.5-2 %
+    if ((uint64_t)nx * ny * nz >= 768ull * 768ull * 768ull) {
+        h->queues_enabled = true;
+    }
     if (const char *e = getenv("CT_NO_ADVANCE")) {
         h->no_advance = atoi(e) != 0;
     }

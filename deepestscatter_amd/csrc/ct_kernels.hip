@@ -738,8 +738,10 @@ hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, flo
 //
 // The queue hands out jobs = (pixel group, subframe range); a group is 64 consecutive entries of
 // the list of this shard's box-hitting pixels (tile-Morton order).  See BatchArgs for the order.
+// (6 waves per SIMD = 3 blocks of 512 threads per CU: the register allocator must stay within 80 VGPRs.  It
+// uses 75 today; an edit of take_job once moved it to 85 and cost a third of the occupancy, hence the bound.)
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(512) void render_persistent_kernel(DevScene sc, BatchArgs ba)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void render_persistent_kernel(DevScene sc, BatchArgs ba)
 {
     __shared__ MieLdsFull lds;
     load_tables(sc, lds);

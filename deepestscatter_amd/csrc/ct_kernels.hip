@@ -1376,7 +1376,7 @@ hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primar
 }
 
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256) void render_delta_kernel(DevScene sc, BatchArgs ba)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void render_delta_kernel(DevScene sc, BatchArgs ba)
 {
     __shared__ MieLds lds;
     load_tables(sc, lds);

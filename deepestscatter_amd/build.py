@@ -63,7 +63,8 @@ def build_cli(force: bool = False, verbose: bool = False) -> Path:
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     if force or needs_build():
-        cmd = [hipcc(), *FLAGS, "-o", str(LIB), *[str(CSRC / s) for s in SOURCES]]
+        # CT_EXTRA_FLAGS: e.g. -DCT_DEBUG_BOUNDS (device-side index checks that report instead of faulting)
+        cmd = [hipcc(), *FLAGS, *os.environ.get("CT_EXTRA_FLAGS", "").split(), "-o", str(LIB), *[str(CSRC / s) for s in SOURCES]]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=str(CSRC))

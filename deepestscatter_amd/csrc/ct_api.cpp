@@ -513,7 +513,7 @@ static int create_impl(const CtScene *s, CtHandle h)
         h->continuation = atoi(e) != 0;
     }
     for (auto &sl : h->slots) {
-        HIPCHK(h, dmalloc(&sl.cont, h->cont_capacity * kContWords));
+        HIPCHK(h, dmalloc(&sl.cont, h->cont_capacity * (s->estimator == CT_EST_DELTA ? kContWordsDelta : kContWords)));
         HIPCHK(h, dmalloc(&sl.queue, kQueueWords));
         for (hipEvent_t *e : { &sl.ev_in, &sl.ev_start, &sl.ev_done, &sl.ev_acc0, &sl.ev_acc1 }) {
             HIPCHK(h, hipEventCreate(e));
@@ -1076,7 +1076,11 @@ static int flush(CtHandle h)
         HIPCHK(h, hipMemsetAsync(h->d_cont_count + 2, 0, sizeof(uint32_t), h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
         HIPCHK(h, hipEventRecord(h->ev_flush0, h->stream));
-        HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+        if (h->scene.estimator == CT_EST_DELTA) {
+            HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
+        } else {
+            HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+        }
         HIPCHK(h, hipEventRecord(h->ev_flush1, h->stream));
         const int rc = enqueue_accumulate(h, sl, slot_frames(h, slot), false);
         if (rc != CT_OK) {
@@ -1251,7 +1255,7 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             }
             const auto t2 = std::chrono::steady_clock::now();
             if (rc == CT_OK) {
-                const bool suspend = !wait && h->continuation && !simple && h->scene.estimator == CT_EST_MARCH;
+                const bool suspend = !wait && h->continuation && !simple;
                 rc = submit_batch(h, slot, nullptr, first_subframe_id + done, S, true, suspend);
             }
             if (trace) {

@@ -179,6 +179,13 @@ CT_DEV uint2 load_footprint_meta(const DevScene &sc, const uint8_t *bricks, int3
     const uint32_t x = (uint32_t)(ix + sc.brick_bias), y = (uint32_t)(iy + sc.brick_bias), z = (uint32_t)(iz + sc.brick_bias);
     const uint32_t brick = __umul24(z >> 2, (uint32_t)sc.brick_gxy) + __umul24(y >> 2, (uint32_t)sc.brick_gx) + (x >> 2);
     const uint32_t local = __umul24(z & 3u, 25u) + __umul24(y & 3u, 5u) + (x & 3u);
+#ifdef CT_DEBUG_BOUNDS
+    if ((x >> 2) >= (uint32_t)sc.brick_gx || (y >> 2) >= (uint32_t)sc.brick_gy || (z >> 2) >= (uint32_t)sc.brick_gz) {
+        printf("CT_DEBUG_BOUNDS footprint texel (%d,%d,%d) outside the brick grid\n", ix, iy, iz);
+        meta = 0u;
+        return make_uint2(0u, 0u);
+    }
+#endif
     const uint8_t *base = bricks + ((size_t)brick << 7);
     const uint8_t *p = base + local;
     uint2 a, c;
@@ -235,6 +242,20 @@ CT_DEV uint2 fetch_cell(const DevScene &sc, const uint8_t *bricks, f3 p, uint32_
 {
     const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
     return load_footprint_meta(sc, bricks, floor_to_int(x), floor_to_int(y), floor_to_int(z), meta);
+}
+
+// For the DELTA flights, which run to the edge of the brick grid: a position within an ulp of the grid's
+// outer faces may round into a brick that does not exist, so the texel index is clamped to the grid.  The
+// value is unchanged: out there the volume's clamp-to-edge makes both texels of the clamped axis equal, and
+// the filter of two equal texels is that texel whatever the weight.
+CT_DEV uint2 fetch_cell_in_grid(const DevScene &sc, const uint8_t *bricks, f3 p, uint32_t &meta)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    const int32_t lo = -sc.brick_bias;
+    const int32_t ix = min(max(floor_to_int(x), lo), 4 * sc.brick_gx - 1 + lo);
+    const int32_t iy = min(max(floor_to_int(y), lo), 4 * sc.brick_gy - 1 + lo);
+    const int32_t iz = min(max(floor_to_int(z), lo), 4 * sc.brick_gz - 1 + lo);
+    return load_footprint_meta(sc, bricks, ix, iy, iz, meta);
 }
 
 CT_DEV uint2 fetch_cell_m(const DevScene &sc, f3 p, uint32_t &meta)

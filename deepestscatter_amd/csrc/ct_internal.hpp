@@ -12,6 +12,7 @@ constexpr int kTile = 8;            // pixel tile edge: 8x8 = one wave of primar
 constexpr int kCounterCount = 6;    // paths, box_hits, density, inscatter, scatter, capped
 constexpr int kStatCount = 64;      // scheduler diagnostics (ct_debug_stats)
 constexpr int kContWords = 16;      // words of a suspended path (render_persistent_kernel)
+constexpr int kContWordsDelta = 32; // the same for render_delta_kernel (its DDA state rides along)
 constexpr int kQueueFlag = 32;       // word of the queue array (its own 128-B line) that says "job list empty"
 constexpr int kQueueWords = 64;      // size of a queue array
 constexpr int kQueues = 8;          // one job queue per XCD (MI355X: 8 XCDs, each with its own L2)

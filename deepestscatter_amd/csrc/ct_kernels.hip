@@ -1394,7 +1394,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0;
 
+    // ---------------- path continuation, as in render_persistent_kernel (kContWordsDelta words per path) ----------------
+    bool resumed = false;
+    if (ba.cont_in) {
+        const uint32_t total = __builtin_amdgcn_readfirstlane(*ba.cont_in_count);
+        uint32_t base = 0;
+        if (lane == 0) {
+            base = atomicAdd(ba.cont_cursor, 64u);
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + lane < total) {
+            const uint4 *e = (const uint4 *)(ba.cont_in + (size_t)(base + lane) * kContWordsDelta);
+            const uint4 w0 = e[0], w1 = e[1], w2 = e[2], w3 = e[3], w4 = e[4], w5 = e[5], w6 = e[6];
+            pos = mk3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
+            dir = mk3(__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y));
+            rad = mk3(__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x));
+            seed = w2.y;
+            out_idx = w2.z;
+            depth = w2.w & 0xffffu;
+            state = (int)(w2.w >> 24);
+            dda.org = mk3(__uint_as_float(w3.x), __uint_as_float(w3.y), __uint_as_float(w3.z));
+            dda.t = __uint_as_float(w3.w);
+            dda.tmax = mk3(__uint_as_float(w4.x), __uint_as_float(w4.y), __uint_as_float(w4.z));
+            dda.bx = (int32_t)w4.w;
+            dda.tdelta = mk3(__uint_as_float(w5.x), __uint_as_float(w5.y), __uint_as_float(w5.z));
+            dda.by = (int32_t)w5.w;
+            dda.bz = (int32_t)w6.x;
+            dda.meta = w6.y;
+            resumed = true;
+        }
+    }
+    const bool may_suspend = ba.cont_out != nullptr;
+    uint32_t visit = 0;
+
     for (;;) {
+        visit += 1;
+        if (may_suspend && !drained && sc.hint_period != 0u && (visit & (sc.hint_period - 1u)) == 0u) {
+            const uint32_t empty = __builtin_amdgcn_readfirstlane(__atomic_load_n(ba.queue + kQueueFlag, __ATOMIC_RELAXED));
+            if (empty != 0u && q_next == q_end) {
+                drained = true;
+            }
+        }
         // ---------------- regenerate ----------------
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
@@ -1437,6 +1477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
                         seed = tea4(__float_as_uint(p1.w), ba.first_subframe + s);
                         rad = mk3(0, 0, 0);
                         depth = 0;
+                        resumed = false;
                         if (MODE == 1) {
                             dir = new_direction(lds.cdf, lds.guide, seed, dir);
                         }
@@ -1466,6 +1507,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
                             }
                             state = ST_MARCH;
                         } else {
+#ifdef CT_DEBUG_BOUNDS
+                            if (!resumed && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to the previous batch's half)
+                                printf("CT_DEBUG_BOUNDS frames[%u] outside the batch (offset %u, S %u, stride %u)\n", out_idx, ba.out_offset, ba.S, ba.frame_stride);
+                                out_idx = ba.out_offset;
+                            }
+#endif
                             ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
                         }
                     }
@@ -1547,8 +1594,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
                             dda.t = dda.t + dt;
                             const f3 p = mk3(fmaf(dir.x, dda.t, dda.org.x), fmaf(dir.y, dda.t, dda.org.y),
                                              fmaf(dir.z, dda.t, dda.org.z));
+#ifdef CT_DEBUG_BOUNDS
+                            {
+                                const int32_t qx = (floor_to_int(fmaf(p.x, sc.sx, -0.5f)) + sc.brick_bias) >> 2;
+                                const int32_t qy = (floor_to_int(fmaf(p.y, sc.sy, -0.5f)) + sc.brick_bias) >> 2;
+                                const int32_t qz = (floor_to_int(fmaf(p.z, sc.sz, -0.5f)) + sc.brick_bias) >> 2;
+                                if (qx < 0 || qy < 0 || qz < 0 || qx >= sc.brick_gx || qy >= sc.brick_gy || qz >= sc.brick_gz) {   // clamped by fetch_cell_in_grid
+                                    printf("CT_DEBUG_BOUNDS visit in brick (%d,%d,%d) but p in (%d,%d,%d): t %g dt %g t_exit %g tmax %g %g %g dir %g %g %g org %g %g %g M %u\n",
+                                           dda.bx, dda.by, dda.bz, qx, qy, qz, (double)dda.t, (double)dt, (double)t_exit,
+                                           (double)dda.tmax.x, (double)dda.tmax.y, (double)dda.tmax.z, (double)dir.x, (double)dir.y,
+                                           (double)dir.z, (double)dda.org.x, (double)dda.org.y, (double)dda.org.z, M);
+                                }
+                            }
+#endif
                             uint32_t meta_unused;
-                            const uint2 cell = fetch_cell(sc, sc.dbricks, p, meta_unused);
+                            const uint2 cell = fetch_cell_in_grid(sc, sc.dbricks, p, meta_unused);
                             c_dl += 1;
                             if (STATS) {
                                 st_fetch += 1;
@@ -1571,6 +1631,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
                     }
                 }
                 if (ended) {
+#ifdef CT_DEBUG_BOUNDS
+                    if (!resumed && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to the previous batch's half)
+                        printf("CT_DEBUG_BOUNDS frames[%u] outside the batch (offset %u, S %u, stride %u)\n", out_idx, ba.out_offset, ba.S, ba.frame_stride);
+                        out_idx = ba.out_offset;
+                    }
+#endif
                     ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
                     if (ba.cost) {
                         atomicAdd(&ba.cost[group], depth);
@@ -1594,12 +1660,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
             }
         }
         if (finished) {
+#ifdef CT_DEBUG_BOUNDS
+            if (!resumed && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to the previous batch's half)
+                printf("CT_DEBUG_BOUNDS frames[%u] outside the batch (offset %u, S %u, stride %u)\n", out_idx, ba.out_offset, ba.S, ba.frame_stride);
+                out_idx = ba.out_offset;
+            }
+#endif
             ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
             if (ba.cost) {
                 atomicAdd(&ba.cost[group], depth);
                 atomicMax(&ba.cost_max[group], depth);
             }
             state = ST_IDLE;
+        }
+        // ---------------- suspend (see render_persistent_kernel) ----------------
+        if (may_suspend && drained && q_next == q_end) {
+            const bool mine = state != ST_IDLE && !resumed;
+            const uint64_t live = __builtin_amdgcn_ballot_w64(mine);
+            if (live != 0ull) {
+                const uint32_t n = (uint32_t)__builtin_popcountll(live);
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(live)) {
+                    base = atomicAdd(ba.cont_out_count, n);
+                    if (base + n > ba.cont_capacity) {
+                        atomicSub(ba.cont_out_count, n);
+                        base = 0xffffffffu;
+                    }
+                }
+                base = __builtin_amdgcn_readlane(base, __builtin_ctzll(live));
+                if (mine && base != 0xffffffffu) {
+                    uint4 *e = (uint4 *)(ba.cont_out + (size_t)(base + lane_rank(live)) * kContWordsDelta);
+                    e[0] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), __float_as_uint(dir.x));
+                    e[1] = make_uint4(__float_as_uint(dir.y), __float_as_uint(dir.z), __float_as_uint(rad.x), __float_as_uint(rad.y));
+                    e[2] = make_uint4(__float_as_uint(rad.z), seed, out_idx, depth | ((uint32_t)state << 24));
+                    e[3] = make_uint4(__float_as_uint(dda.org.x), __float_as_uint(dda.org.y), __float_as_uint(dda.org.z), __float_as_uint(dda.t));
+                    e[4] = make_uint4(__float_as_uint(dda.tmax.x), __float_as_uint(dda.tmax.y), __float_as_uint(dda.tmax.z), (uint32_t)dda.bx);
+                    e[5] = make_uint4(__float_as_uint(dda.tdelta.x), __float_as_uint(dda.tdelta.y), __float_as_uint(dda.tdelta.z), (uint32_t)dda.by);
+                    e[6] = make_uint4((uint32_t)dda.bz, dda.meta, 0u, 0u);
+                    state = ST_IDLE;
+                }
+            }
         }
     }
 

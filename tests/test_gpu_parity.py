@@ -388,6 +388,30 @@ def test_delta_brick_replay_is_bit_exact(dims, radius):
     tr.close()
 
 
+def test_delta_flight_at_the_edge_of_the_brick_grid():
+    """A volume without a zero border: its clamp-to-edge values fill the apron bricks, so Woodcock flights
+    keep drawing tentative collisions all the way to the outer face of the brick grid, where a position
+    within an ulp of the face rounds into a brick that does not exist (found by tools/soak_continuation.py
+    as a GPU memory fault: dims (14,5,34), 288x141).  The fetch clamps the texel index to the grid; the
+    value is the oracle's clamp-to-edge one."""
+    rng = np.random.default_rng(84)
+    tex = rng.integers(0, 256, (34, 5, 14)).astype(np.uint8)
+    w, h = 288, 141
+    eye = (0.13926167059960207, -0.06436481666191757, 1.1023804706499314)
+    for mode, depth in ((2, 50), (0, 300)):
+        tr, orc = make_pair(tex, w, h, mode=mode, estimator=1, cloud_size_m=20000.0, sample_step=1 / 512, max_depth=depth,
+                            light_direction=(-0.14960121569810259, -1.138979689131218, 0.7051263148774981))
+        U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
+        tr.set_camera(eye, U, V, W)
+        orc.set_camera(eye, U, V, W)
+        mean, m2 = orc.render(3)
+        tr.render_accumulate(1, 2)
+        tr.render_accumulate_async(3, 1)
+        assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2)
+        assert tr.counters() == orc.counters.as_dict()
+        tr.close()
+
+
 def test_delta_shards_and_point_tasks():
     tex = sphere_volume(32, seed=35)
     w, h = 40, 24

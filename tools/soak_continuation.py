@@ -19,7 +19,7 @@ for case in range(cases):
     kw, eye = _random_scene(rng)
     tex = kw.pop("tex"); kw.pop("width"); kw.pop("height")
     w, h = int(rng.integers(96, 320)), int(rng.integers(64, 256))
-    kw["estimator"] = 0
+    kw["estimator"] = int(rng.random() < 0.4)
     kw["cloud_size_m"] = float(rng.choice([7000.0, 20000.0, 40000.0]))
     kw["sample_step"] = 1.0 / 512
     kw["max_depth"] = int(rng.choice([50, 300, 2000]))

@@ -162,6 +162,12 @@ CT_DEV uint2 load_footprint(const DevScene &sc, const uint8_t *bricks, int32_t i
     const uint32_t x = (uint32_t)(ix + sc.brick_bias), y = (uint32_t)(iy + sc.brick_bias), z = (uint32_t)(iz + sc.brick_bias);
     const uint32_t brick = __umul24(z >> 2, (uint32_t)sc.brick_gxy) + __umul24(y >> 2, (uint32_t)sc.brick_gx) + (x >> 2);
     const uint32_t local = __umul24(z & 3u, 25u) + __umul24(y & 3u, 5u) + (x & 3u);
+#ifdef CT_DEBUG_BOUNDS
+    if ((x >> 2) >= (uint32_t)sc.brick_gx || (y >> 2) >= (uint32_t)sc.brick_gy || (z >> 2) >= (uint32_t)sc.brick_gz) {
+        printf("CT_DEBUG_BOUNDS footprint texel (%d,%d,%d) outside the brick grid\n", ix, iy, iz);
+        return make_uint2(0u, 0u);
+    }
+#endif
     const uint8_t *p = bricks + (((size_t)brick << 7) | local);
     uint2 a, c;
     __builtin_memcpy(&a, p, 8);       // bytes o+0, o+1 (y) and o+5, o+6 (y+1)
@@ -206,6 +212,13 @@ CT_DEV uint2 load_footprint_m(const DevScene &sc, int32_t ix, int32_t iy, int32_
     const uint32_t lx = x - __umul24(bx, 3u);
     const uint32_t brick = __umul24(z >> 2, (uint32_t)sc.m_gxy) + __umul24(y >> 2, (uint32_t)sc.m_gx) + bx;
     const uint32_t local = __umul24(z & 3u, 25u) + __umul24(y & 3u, 5u) + lx;
+#ifdef CT_DEBUG_BOUNDS
+    if (bx >= (uint32_t)sc.m_gx || (y >> 2) >= (uint32_t)sc.brick_gy || (z >> 2) >= (uint32_t)sc.brick_gz) {
+        printf("CT_DEBUG_BOUNDS march-brick texel (%d,%d,%d) outside the grid\n", ix, iy, iz);
+        meta = 0u;
+        return make_uint2(0u, 0u);
+    }
+#endif
     const uint8_t *p = sc.mbricks + (((size_t)brick << 7) | local);
     uint2 a, c;
     __builtin_memcpy(&a, p, 8);       // t_lx, t_lx+1 of row ly at bytes 0,1; of row ly+1 at 5,6; M at 4-lx

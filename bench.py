@@ -7,13 +7,13 @@ reduce of the accumulated radiance buffer).
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one progressive batch of --spp-per-step (default 256 x n_gpus) subframes of the whole
+A "step" = one progressive batch of --spp-per-step (default 512 x n_gpus) subframes of the whole
 frame: estimator kernel + Welford accumulate kernel, plus (N>1) the reduce of the W*H float4
-radiance buffer to rank 0.  The default run (4 steps) is exactly one 1024-spp image of
-BASELINE.json's configuration in four progressive updates.  (The reference updates its display
+radiance buffer to rank 0.  Two steps are one 1024-spp image of BASELINE.json's configuration (512 subframes
+of a 1024^2 frame are what the 8 GiB per-batch sample scratch holds).  (The reference updates its display
 every 10 subframes and saves every 40, Camera.cpp:189,211; a launch ends with a tail of waves that
 finish its long paths unless it may hand them to the next launch, which is what the enqueued steps of this
-benchmark do: 2280 Msamples/s at 64 spp per launch, 2540 at 128, 2680 at 256, 2770 at 512; waiting for every
+benchmark do: 2280 Msamples/s at 64 spp per launch, 2540 at 128, 2730 at 256, 2855 at 512; waiting for every
 step: 1690, 2110, 2480, 2590.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
 before the timed region and resident in HBM).  Prints ONE JSON line on rank 0.
 """
@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp-per-step", type=int, default=0,
                     help="subframes per progressive batch (one estimator launch + one accumulate launch); "
-                         "default 256 x n_gpus, i.e. a constant number of samples per GPU per launch")
+                         "default 512 x n_gpus, i.e. a constant number of samples per GPU per launch")
     ap.add_argument("--mode", type=int, default=0, help="0 totalRadiance (Mie multi-scatter + NEE)")
     ap.add_argument("--estimator", type=int, default=0, choices=(0, 1),
                     help="0 MARCH = the reference's free-flight sampler (the parity path, default); "
@@ -120,7 +120,7 @@ def main():
             dist.init_process_group(args.backend)
 
     W, H = args.width, args.height
-    S = args.spp_per_step if args.spp_per_step > 0 else 256 * world
+    S = args.spp_per_step if args.spp_per_step > 0 else 512 * world
     t_setup = time.perf_counter()
     tex = ds.make_procedural_cloud(args.volume)
     flags = _lib.CT_FLAG_SIMPLE_KERNEL if args.simple_kernel else 0
@@ -230,7 +230,7 @@ def main():
         "metric": "Msamples/s (rays x spp) at 512^3 vol, 1024^2 frame; HBM GB/s vs roofline",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        # every GPU renders its 1/N of the tiles for 256 x N subframes per step: constant work per GPU per step
+        # every GPU renders its 1/N of the tiles for 512 x N subframes per step: constant work per GPU per step
         "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {

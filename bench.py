@@ -235,7 +235,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{args.volume}^3 procedural density, {W}x{H}, progressive, {S} spp per step "
-                        f"(BASELINE.json configs[{2 if world == 1 else 3}]: 1024 spp job = {max(1024 // max(S, 1), 1)} such steps), "
+                        f"(BASELINE.json configs[{2 if world == 1 else 3}]: a 1024 spp job is {1024 / max(S, 1):g} such steps), "
                         f"mode {('totalRadiance','multipleScatterSunRadiance','singleScatterSunRadiance')[args.mode]} "
                         "(Mie multi-scatter + NEE), estimator "
                         f"{('MARCH (reference-faithful)', 'DELTA (Woodcock, brick majorants)')[args.estimator]}, max_depth 2000",

@@ -32,7 +32,7 @@ struct CtHandle_ {
     bool camera_set = false;
 
     // device memory
-    uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr, *d_majorant = nullptr;
+    uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr, *d_majorant = nullptr, *d_maj_cells = nullptr;
     uint8_t *d_dbricks = nullptr, *d_ibricks = nullptr, *d_mbricks = nullptr;
     uint8_t *d_pyramid = nullptr;     // density mip pyramid, built on first use (ct_collect_descriptors)
     MipPyramid pyramid{};
@@ -235,7 +235,7 @@ static void release(CtHandle h)
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->slots[0].queue, h->slots[1].queue, h->slots[0].cont, h->slots[1].cont, h->d_cont_count, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->slots[0].queue, h->slots[1].queue, h->slots[0].cont, h->slots[1].cont, h->d_cont_count, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
         if (p) {
@@ -462,6 +462,31 @@ static int create_impl(const CtScene *s, CtHandle h)
                                     h->d_dist_tmp, h->d_majorant, h->stream));
         HIPCHK(h, launch_brick_meta(h->d_dist, h->d_majorant, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz,
                                     h->d_dbricks, h->stream));
+    }
+    if (s->estimator == CT_EST_DELTA) {
+        // majorant cells of the DELTA grid (orc_majorant_grid / orc_build_majorants in the oracle): cells of
+        // 2^shift texels over [-bias, n + bias), the smallest shift whose grid fits the kernel's LDS array
+        int shift = 2;
+        int64_t cgx, cgy, cgz;
+        for (;; shift++) {
+            const int64_t c = 1ll << shift;
+            cgx = ((int64_t)nx + 2 * bbias + c - 1) >> shift;
+            cgy = ((int64_t)ny + 2 * bbias + c - 1) >> shift;
+            cgz = ((int64_t)nz + 2 * bbias + c - 1) >> shift;
+            if (cgx * cgy * cgz <= kMajCellsMax) {
+                break;
+            }
+        }
+        const size_t cells = (size_t)(cgx * cgy * cgz);
+        HIPCHK(h, dmalloc(&h->d_maj_cells, (cells + 3) & ~(size_t)3)); // the kernel copies whole words
+        HIPCHK(h, hipMemsetAsync(h->d_maj_cells, 0, (cells + 3) & ~(size_t)3, h->stream));
+        HIPCHK(h, launch_majorant_cells(h->d_density, nx, ny, nz, bbias, shift, (int)cgx, (int)cgy, (int)cgz, h->d_maj_cells,
+                                        h->stream));
+        d.maj_cells = h->d_maj_cells;
+        d.mc_shift = shift;
+        d.mc_gx = (int32_t)cgx;
+        d.mc_gy = (int32_t)cgy;
+        d.mc_gz = (int32_t)cgz;
     }
     HIPCHK(h, launch_inscatter(d, h->d_inscatter, h->stream));
     HIPCHK(h, launch_build_bricks(h->d_inscatter, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_ibricks, h->stream));

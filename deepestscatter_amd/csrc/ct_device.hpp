@@ -45,6 +45,7 @@ constexpr int kGuideN = 4096;         // buckets of the CDF guide table
 constexpr float kFracMax = 0x1.fffffep-1f;
 constexpr int kBrick = 4;             // texels per edge of a free-space brick
 constexpr int kBrickShift = 2;
+constexpr int kMajCellsMax = 40960;   // cells of the DELTA majorant grid (one byte each, LDS-resident)
 
 // All uniforms of the path: the OptiX variable scopes of SURVEY section 8b, flattened.
 struct DevScene {
@@ -78,6 +79,12 @@ struct DevScene {
     // bit 7 = "interior" for the row's bases (1 <= base <= N-3 on every axis: isInBox holds for
     // every position based there and for a scatter position backed off from it).
     const uint8_t *mbricks;
+    // The DELTA estimator's majorants: one byte per cubic cell of 2^mc_shift texels over the texel range
+    // [-brick_bias, n + brick_bias) per axis, x-fastest.  mc_shift is the smallest value >= 2 for which the grid
+    // has at most kMajCellsMax cells, so that every block keeps the whole grid in LDS and a flight crosses cells
+    // without touching memory (oracle/ct_oracle.c, DELTA header: same grid, same majorants).
+    const uint8_t *maj_cells;
+    int32_t mc_shift, mc_gx, mc_gy, mc_gz;
     int32_t m_bias_x;        // x bias of the 3-texel brick columns (multiple of 3)
     int32_t m_gx, m_gxy;     // bricks per row / per slice of mbricks (y and z use brick_gy/gz, brick_bias)
     int32_t nx, ny, nz;    // texels

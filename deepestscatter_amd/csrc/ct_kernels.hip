@@ -1252,57 +1252,55 @@ hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const fl
 }
 
 // =============================================================================================
-// DELTA estimator: Woodcock tracking over the brick majorants (BASELINE.json north_star; not the
+// DELTA estimator: Woodcock tracking over a grid of majorant cells (BASELINE.json north_star; not the
 // reference's sampler -- the oracle twin is delta_flight() in oracle/ct_oracle.c, whose header
-// states the algorithm).  Same persistent wave scheduler; the "march" phase becomes one tracking
-// visit per lane with exactly one dependent load:
-//     current brick empty (M == 0)  -> cross max(D-1, 1) bricks by replaying the DDA steps (every
-//                                      brick within Chebyshev distance D-1 is free, so the oracle's
-//                                      plain DDA finds M == 0 in each and does the same arithmetic),
-//                                      then load the meta bytes of the brick reached;
-//     M > 0                          -> draw dt = -log(1-u)/sigma_bar; if it leaves the brick, cross
-//                                      one brick and load its meta bytes; otherwise advance, load the
-//                                      footprint at p = fma(dir, t, origin) and accept the collision
-//                                      when u' * sigma_bar < sigma(p).
+// states the algorithm).  Same persistent wave scheduler.  The majorant grid (DevScene::maj_cells, cells
+// of 2^mc_shift texels, at most kMajCellsMax of them) is copied to LDS by every block, so the DDA that
+// carries a flight from cell to cell reads no memory; the "march" phase becomes a tracking visit:
+//     walk cells (up to kDeltaHops per visit): M == 0 -> cross; M > 0 -> draw dt = -log(1-u)/sigma_bar,
+//     and if it leaves the cell, cross (the exponential is memoryless);
+//     otherwise advance, load the footprint at p = fma(dir, t, origin) -- the visit's one global load --
+//     and accept the collision when u' * sigma_bar < sigma(p).
 // =============================================================================================
+constexpr uint32_t kDeltaHops = 8;
+constexpr int kDeltaThreads = 768;
+
 struct Dda {
     f3 org;            // origin of the flight (box coordinates), positions are fma(dir, t, org)
     float t;
-    f3 tmax, tdelta;   // ray parameter at the next brick boundary per axis / between boundaries
+    f3 tmax, tdelta;   // ray parameter at the next cell boundary per axis / between boundaries
     int32_t bx, by, bz;
-    uint32_t meta;     // meta bytes of the brick (bx,by,bz): D | interior << 7 | M << 8
 };
 
-CT_DEV uint32_t load_brick_meta(const DevScene &sc, int32_t bx, int32_t by, int32_t bz)
+CT_DEV bool cell_in_grid(const DevScene &sc, const Dda &d)
 {
-    const uint32_t brick = __umul24((uint32_t)bz, (uint32_t)sc.brick_gxy) + __umul24((uint32_t)by, (uint32_t)sc.brick_gx) + (uint32_t)bx;
-    const uint8_t *p = sc.dbricks + ((size_t)brick << 7) + 125;
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8);
+    return (uint32_t)d.bx < (uint32_t)sc.mc_gx && (uint32_t)d.by < (uint32_t)sc.mc_gy && (uint32_t)d.bz < (uint32_t)sc.mc_gz;
 }
 
-CT_DEV bool brick_in_grid(const DevScene &sc, const Dda &d)
+CT_DEV uint32_t cell_index(const DevScene &sc, const Dda &d)
 {
-    return d.bx >= 0 && d.by >= 0 && d.bz >= 0 && d.bx < sc.brick_gx && d.by < sc.brick_gy && d.bz < sc.brick_gz;
+    return __umul24(__umul24((uint32_t)d.bz, (uint32_t)sc.mc_gy) + (uint32_t)d.by, (uint32_t)sc.mc_gx) + (uint32_t)d.bx;
 }
 
-// DDA set-up of a flight from `pos` along `dir`; leaves the meta load in flight.
+// DDA set-up of a flight from `pos` along `dir`.
 CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
 {
     d.org = pos;
     d.t = 0.0f;
     const float tpx = fmaf(pos.x, sc.sx, -0.5f), tpy = fmaf(pos.y, sc.sy, -0.5f), tpz = fmaf(pos.z, sc.sz, -0.5f);
     const float vx = dir.x * sc.sx, vy = dir.y * sc.sy, vz = dir.z * sc.sz;
-    d.bx = (floor_to_int(tpx) + sc.brick_bias) >> 2;
-    d.by = (floor_to_int(tpy) + sc.brick_bias) >> 2;
-    d.bz = (floor_to_int(tpz) + sc.brick_bias) >> 2;
+    d.bx = (floor_to_int(tpx) + sc.brick_bias) >> sc.mc_shift;
+    d.by = (floor_to_int(tpy) + sc.brick_bias) >> sc.mc_shift;
+    d.bz = (floor_to_int(tpz) + sc.brick_bias) >> sc.mc_shift;
     const float inf = __uint_as_float(0x7f800000u);
+    const float edge = (float)(1 << sc.mc_shift);
     auto axis = [&](int32_t B, float TP, float V, float &TMAX, float &TDELTA) {
         if (V > 0.0f) {
-            TMAX = ((float)(((B + 1) << 2) - sc.brick_bias) - TP) / V;
-            TDELTA = 4.0f / V;
+            TMAX = ((float)(((B + 1) << sc.mc_shift) - sc.brick_bias) - TP) / V;
+            TDELTA = edge / V;
         } else if (V < 0.0f) {
-            TMAX = ((float)((B << 2) - sc.brick_bias) - TP) / V;
-            TDELTA = 4.0f / -V;
+            TMAX = ((float)((B << sc.mc_shift) - sc.brick_bias) - TP) / V;
+            TDELTA = edge / -V;
         } else {
             TMAX = inf;
             TDELTA = inf;
@@ -1311,10 +1309,9 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
     axis(d.bx, tpx, vx, d.tmax.x, d.tdelta.x);
     axis(d.by, tpy, vy, d.tmax.y, d.tdelta.y);
     axis(d.bz, tpz, vz, d.tmax.z, d.tdelta.z);
-    d.meta = brick_in_grid(sc, d) ? load_brick_meta(sc, d.bx, d.by, d.bz) : 0u;
 }
 
-// One brick crossing: t = exit parameter, step along the axis with the smallest tmax
+// One cell crossing: t = exit parameter, step along the axis with the smallest tmax
 // (ties: x before y before z), exactly like the oracle.
 CT_DEV void dda_cross(Dda &d, f3 dir)
 {
@@ -1332,8 +1329,8 @@ CT_DEV void dda_cross(Dda &d, f3 dir)
     }
 }
 
-// The DELTA twin of primary_advance_kernel: the brick DDA of a primary ray draws no random number before
-// it reaches the first brick with a non-zero majorant (or leaves the grid), so that walk is the same
+// The DELTA twin of primary_advance_kernel: the cell DDA of a primary ray draws no random number before
+// it reaches the first cell with a non-zero majorant (or leaves the grid), so that walk is the same
 // for every sample of the pixel.  It is done once per pose with the tracking visit's own operations;
 // advance[4p .. 4p+3] = the Dda state a sample starts its first visit with.
 __global__ __launch_bounds__(256) void primary_advance_delta_kernel(DevScene sc, const float4 *__restrict__ primary,
@@ -1350,22 +1347,47 @@ __global__ __launch_bounds__(256) void primary_advance_delta_kernel(DevScene sc,
     Dda d{};
     if (p0.w != 0.f && in_box(sc, pos)) {
         dda_begin(sc, d, pos, dir);
-        for (int it = 0; it < 65536; it++) {
-            if (!brick_in_grid(sc, d) || (d.meta >> 8) != 0u) {
-                break;
-            }
-            const uint32_t D = d.meta & 0x7fu;
-            const uint32_t n = D > 1u ? D - 1u : 1u;
-            for (uint32_t i = 0; i < n; i++) {
-                dda_cross(d, dir);
-            }
-            d.meta = brick_in_grid(sc, d) ? load_brick_meta(sc, d.bx, d.by, d.bz) : 0u;
+        while (cell_in_grid(sc, d) && sc.maj_cells[cell_index(sc, d)] == 0u) {
+            dda_cross(d, dir); // (every crossing moves one cell: the walk ends at the grid's faces at the latest)
         }
     }
     advance[4 * p] = make_float4(d.org.x, d.org.y, d.org.z, d.t);
     advance[4 * p + 1] = make_float4(d.tmax.x, d.tmax.y, d.tmax.z, __int_as_float(d.bx));
     advance[4 * p + 2] = make_float4(d.tdelta.x, d.tdelta.y, d.tdelta.z, __int_as_float(d.by));
-    advance[4 * p + 3] = make_float4(__int_as_float(d.bz), __uint_as_float(d.meta), 0.f, 0.f);
+    advance[4 * p + 3] = make_float4(__int_as_float(d.bz), 0.f, 0.f, 0.f);
+}
+
+// Majorant of every cell of the DELTA grid: the max of the texels [lo-1, lo+C+1]^3 (clamped), one block
+// per cell (orc_build_majorants in the oracle).
+__global__ __launch_bounds__(256) void majorant_cells_kernel(const uint8_t *__restrict__ texels, int nx, int ny, int nz, int bias,
+                                                             int shift, int gx, int gy, uint8_t *__restrict__ out)
+{
+    const int cx = blockIdx.x, cy = blockIdx.y, cz = blockIdx.z;
+    const int C = 1 << shift, w = C + 3;
+    const int x0 = C * cx - bias - 1, y0 = C * cy - bias - 1, z0 = C * cz - bias - 1;
+    uint32_t m = 0;
+    for (int i = threadIdx.x; i < w * w * w; i += 256) {
+        const int lx = i % w, ly = (i / w) % w, lz = i / (w * w);
+        const int x = min(max(x0 + lx, 0), nx - 1), y = min(max(y0 + ly, 0), ny - 1), z = min(max(z0 + lz, 0), nz - 1);
+        m = max(m, (uint32_t)texels[((size_t)z * ny + y) * nx + x]);
+    }
+    __shared__ uint32_t red;
+    if (threadIdx.x == 0) {
+        red = 0;
+    }
+    __syncthreads();
+    atomicMax(&red, m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[((size_t)cz * gy + cy) * gx + cx] = (uint8_t)red;
+    }
+}
+
+hipError_t launch_majorant_cells(const uint8_t *texels, int nx, int ny, int nz, int bias, int shift, int gx, int gy, int gz,
+                                 uint8_t *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(majorant_cells_kernel, dim3(gx, gy, gz), dim3(256), 0, stream, texels, nx, ny, nz, bias, shift, gx, gy, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream)
@@ -1376,9 +1398,19 @@ hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primar
 }
 
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void render_delta_kernel(DevScene sc, BatchArgs ba)
+__global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6))) void render_delta_kernel(DevScene sc, BatchArgs ba)
 {
+    // 24 KiB of Mie tables + 40 KiB of majorants per block of 768 threads: two blocks per CU, 6 waves per SIMD
     __shared__ MieLds lds;
+    __shared__ uint32_t maj_words[kMajCellsMax / 4];
+    {
+        const uint32_t words = ((uint32_t)(sc.mc_gx * sc.mc_gy * sc.mc_gz) + 3u) >> 2; // (the array is padded to whole words)
+        const uint32_t *src = (const uint32_t *)sc.maj_cells;
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
+            maj_words[i] = src[i];
+        }
+    }
+    const uint8_t *lds_maj = (const uint8_t *)maj_words;
     load_tables(sc, lds);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -1420,7 +1452,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
             dda.tdelta = mk3(__uint_as_float(w5.x), __uint_as_float(w5.y), __uint_as_float(w5.z));
             dda.by = (int32_t)w5.w;
             dda.bz = (int32_t)w6.x;
-            dda.meta = w6.y;
             resumed = true;
         }
     }
@@ -1501,7 +1532,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
                                 dda.tdelta = mk3(a2.x, a2.y, a2.z);
                                 dda.by = __float_as_int(a2.w);
                                 dda.bz = __float_as_int(a3.x);
-                                dda.meta = __float_as_uint(a3.y);
                             } else {
                                 dda_begin(sc, dda, pos, dir);
                             }
@@ -1566,68 +1596,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
             uint32_t burst = drained ? sc.tail_burst : sc.march_burst;
             for (;;) {
             if (state == ST_MARCH) {
-                bool ended = false;
-                if (!brick_in_grid(sc, dda)) {
-                    ended = true; // left the grid without a collision
-                } else {
-                    const uint32_t M = dda.meta >> 8;
-                    bool crossed = false;
-                    if (M == 0u) {
-                        const uint32_t D = dda.meta & 0x7fu;
-                        const uint32_t n = D > 1u ? D - 1u : 1u;
-                        for (uint32_t i = 0; i < n; i++) {
-                            dda_cross(dda, dir);
-                        }
-                        if (STATS) {
-                            st_skip += n;
-                        }
-                        crossed = true;
-                    } else {
-                        const float sigma_bar = ((float)M * (1.0f / 255.0f)) * sc.density_multiplier;
+                bool ended = false, collide = false;
+                float sigma_bar = 0.0f;
+                for (uint32_t hop = 0; hop < kDeltaHops; hop++) {
+                    if (!cell_in_grid(sc, dda)) {
+                        ended = true; // left the grid without a collision
+                        break;
+                    }
+                    const uint32_t M = lds_maj[cell_index(sc, dda)];
+                    if (M != 0u) {
+                        sigma_bar = ((float)M * (1.0f / 255.0f)) * sc.density_multiplier;
                         const float u = u24_to_float(lcg24(seed));
                         const float dt = -logf_above_one(1.0f - u) / sigma_bar;
                         const float t_exit = fminf(fminf(dda.tmax.x, dda.tmax.y), dda.tmax.z);
-                        if (dda.t + dt >= t_exit) {
-                            dda_cross(dda, dir);
-                            crossed = true;
-                        } else {
+                        if (dda.t + dt < t_exit) {
                             dda.t = dda.t + dt;
-                            const f3 p = mk3(fmaf(dir.x, dda.t, dda.org.x), fmaf(dir.y, dda.t, dda.org.y),
-                                             fmaf(dir.z, dda.t, dda.org.z));
-#ifdef CT_DEBUG_BOUNDS
-                            {
-                                const int32_t qx = (floor_to_int(fmaf(p.x, sc.sx, -0.5f)) + sc.brick_bias) >> 2;
-                                const int32_t qy = (floor_to_int(fmaf(p.y, sc.sy, -0.5f)) + sc.brick_bias) >> 2;
-                                const int32_t qz = (floor_to_int(fmaf(p.z, sc.sz, -0.5f)) + sc.brick_bias) >> 2;
-                                if (qx < 0 || qy < 0 || qz < 0 || qx >= sc.brick_gx || qy >= sc.brick_gy || qz >= sc.brick_gz) {   // clamped by fetch_cell_in_grid
-                                    printf("CT_DEBUG_BOUNDS visit in brick (%d,%d,%d) but p in (%d,%d,%d): t %g dt %g t_exit %g tmax %g %g %g dir %g %g %g org %g %g %g M %u\n",
-                                           dda.bx, dda.by, dda.bz, qx, qy, qz, (double)dda.t, (double)dt, (double)t_exit,
-                                           (double)dda.tmax.x, (double)dda.tmax.y, (double)dda.tmax.z, (double)dir.x, (double)dir.y,
-                                           (double)dir.z, (double)dda.org.x, (double)dda.org.y, (double)dda.org.z, M);
-                                }
-                            }
-#endif
-                            uint32_t meta_unused;
-                            const uint2 cell = fetch_cell_in_grid(sc, sc.dbricks, p, meta_unused);
-                            c_dl += 1;
-                            if (STATS) {
-                                st_fetch += 1;
-                                st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
-                            }
-                            const float sigma = filter_at(sc, cell, p) * sc.density_multiplier;
-                            const float z = u24_to_float(lcg24(seed));
-                            if (z * sigma_bar < sigma) {
-                                pos = p;
-                                if (in_box(sc, pos)) {
-                                    state = ST_BOUNCE;
-                                } else {
-                                    ended = true;
-                                }
-                            }
+                            collide = true;
+                            break;
                         }
                     }
-                    if (crossed) {
-                        dda.meta = brick_in_grid(sc, dda) ? load_brick_meta(sc, dda.bx, dda.by, dda.bz) : 0u;
+                    dda_cross(dda, dir);
+                    if (STATS) {
+                        st_skip += 1;
+                    }
+                }
+                if (collide) {
+                    const f3 p = mk3(fmaf(dir.x, dda.t, dda.org.x), fmaf(dir.y, dda.t, dda.org.y), fmaf(dir.z, dda.t, dda.org.z));
+                    uint32_t meta_unused;
+                    const uint2 cell = fetch_cell_in_grid(sc, sc.dbricks, p, meta_unused);
+                    c_dl += 1;
+                    if (STATS) {
+                        st_fetch += 1;
+                        st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
+                    }
+                    const float sigma = filter_at(sc, cell, p) * sc.density_multiplier;
+                    const float z = u24_to_float(lcg24(seed));
+                    if (z * sigma_bar < sigma) {
+                        pos = p;
+                        if (in_box(sc, pos)) {
+                            state = ST_BOUNCE;
+                        } else {
+                            ended = true;
+                        }
                     }
                 }
                 if (ended) {
@@ -1696,7 +1706,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
                     e[3] = make_uint4(__float_as_uint(dda.org.x), __float_as_uint(dda.org.y), __float_as_uint(dda.org.z), __float_as_uint(dda.t));
                     e[4] = make_uint4(__float_as_uint(dda.tmax.x), __float_as_uint(dda.tmax.y), __float_as_uint(dda.tmax.z), (uint32_t)dda.bx);
                     e[5] = make_uint4(__float_as_uint(dda.tdelta.x), __float_as_uint(dda.tdelta.y), __float_as_uint(dda.tdelta.z), (uint32_t)dda.by);
-                    e[6] = make_uint4((uint32_t)dda.bz, dda.meta, 0u, 0u);
+                    e[6] = make_uint4((uint32_t)dda.bz, 0u, 0u, 0u);
                     state = ST_IDLE;
                 }
             }
@@ -1767,15 +1777,15 @@ hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchSh
 LaunchShape persistent_shape(int device, bool delta)
 {
     hipDeviceProp_t prop;
-    LaunchShape s{ 1024, delta ? 256 : 512 };
+    LaunchShape s{ 1024, delta ? kDeltaThreads : 512 };
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         // as many blocks per CU as the kernel's registers and LDS admit: MARCH 512 threads / 40 KiB,
-        // DELTA 256 threads / 24 KiB
+        // DELTA 768 threads / 64 KiB
         int per_cu = 0;
-        const hipError_t e = delta ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_delta_kernel<0, false>, 256, 0)
+        const hipError_t e = delta ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_delta_kernel<0, false>, kDeltaThreads, 0)
                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_persistent_kernel<0, false>, 512, 0);
         if (e != hipSuccess || per_cu < 1) {
-            per_cu = delta ? 5 : 3;
+            per_cu = delta ? 2 : 3;
         }
         s.blocks = prop.multiProcessorCount * std::min(per_cu, 8);
         if (const char *e = getenv("CT_BLOCKS_PER_CU")) {   // tuning knob for experiments

@@ -202,7 +202,7 @@ typedef struct OrcScene {
      * over per-brick majorants; NOT in the reference -- BASELINE.json north_star / SURVEY section 7.6) */
     int32_t estimator;
     const uint8_t *majorant;       /* orc_build_majorants(), needed for DELTA */
-    int32_t maj_bias, maj_gx, maj_gy, maj_gz;
+    int32_t maj_bias, maj_gx, maj_gy, maj_gz, maj_shift;
 } OrcScene;
 
 typedef struct OrcCounters {
@@ -227,7 +227,7 @@ typedef struct {
     int32_t mode;
     int32_t estimator;
     const uint8_t *maj;
-    int32_t maj_bias, maj_gx, maj_gy, maj_gz;
+    int32_t maj_bias, maj_gx, maj_gy, maj_gz, maj_shift;
 } Ctx;
 
 static void ctx_init(Ctx *c, const OrcScene *s)
@@ -271,6 +271,7 @@ static void ctx_init(Ctx *c, const OrcScene *s)
     c->maj_gx = s->maj_gx;
     c->maj_gy = s->maj_gy;
     c->maj_gz = s->maj_gz;
+    c->maj_shift = s->maj_shift;
 }
 
 /* Exposes the derived uniforms so tests can compare them with the product's. */
@@ -340,53 +341,71 @@ static Event next_scattering_event(const Ctx *c, float optical_distance, v3 pos,
 /* ------------------------------------------------------------------------------------------
  * DELTA estimator (not in the reference): Woodcock tracking of the SAME medium -- sigma(x) =
  * densityMultiplier * trilinear(texture)/255, the field the reference's march samples once per
- * step -- over a grid of 4x4x4-texel bricks with majorants.
+ * step -- over a grid of cubic cells of C = 2^shift texels with majorants.
  *
- *   brick b (per axis) covers base texels [4b - bias, 4b - bias + 3]; its majorant is the max of
- *   the texels [lo-1, lo+5]^3 (clamped): every texel a trilinear footprint based in the brick
+ *   The grid covers the texel range [-bias, n + bias) per axis (bias = the brick grid's apron, a
+ *   multiple of 4).  shift is the smallest value >= 2 for which the grid has at most
+ *   ORC_MAJ_CELLS_MAX cells: the product keeps the whole grid in the LDS of a compute unit, so a
+ *   flight crosses cells without touching memory (16-texel cells for a 512^3 volume).
+ *   cell c (per axis) covers base texels [C*c - bias, C*c - bias + C - 1]; its majorant is the max
+ *   of the texels [lo-1, lo+C+1]^3 (clamped): every texel a trilinear footprint based in the cell
  *   can read, plus one texel of slack on each side for positions that sit on a boundary.
  *   sigma_bar = (float)M * (1/255.f) * densityMultiplier.
  *
  *   flight from pos along dir:  tp = pos*scale - 0.5 (texel coordinates), v = dir*scale;
- *   3-D DDA over the bricks in the ray parameter t (box units): tmax_a = (bound_a - tp_a)/v_a,
- *   tdelta_a = 4/|v_a|.  In a brick with M > 0:  dt = -log(1 - rnd)/sigma_bar; if t + dt reaches
- *   the brick's exit the flight moves on to the next brick (the exponential is memoryless);
+ *   3-D DDA over the cells in the ray parameter t (box units): tmax_a = (bound_a - tp_a)/v_a,
+ *   tdelta_a = C/|v_a|.  In a cell with M > 0:  dt = -log(1 - rnd)/sigma_bar; if t + dt reaches
+ *   the cell's exit the flight moves on to the next cell (the exponential is memoryless);
  *   otherwise t += dt, p = fma(dir, t, pos), sigma = sample(p) [one density lookup], and the
- *   collision is real when rnd * sigma_bar < sigma.  Leaving the brick grid ends the flight
- *   without a collision.  Unbiased for the trilinear medium; the reference's march is an
- *   O(step)-biased estimator of the same free-flight distribution.
+ *   collision is real when rnd * sigma_bar < sigma.  Leaving the grid ends the flight without a
+ *   collision.  Unbiased for the trilinear medium; the reference's march is an O(step)-biased
+ *   estimator of the same free-flight distribution.
  * ------------------------------------------------------------------------------------------ */
-ORC_API void orc_majorant_grid(const uint32_t dims[3], float sample_step, int32_t out_bias_g[4])
+#define ORC_MAJ_CELLS_MAX 40960
+
+/* out = { bias, cells x, cells y, cells z, shift } */
+ORC_API void orc_majorant_grid(const uint32_t dims[3], float sample_step, int32_t out[5])
 {
     const float m = (float)(dims[0] > dims[1] ? (dims[0] > dims[2] ? dims[0] : dims[2]) : (dims[1] > dims[2] ? dims[1] : dims[2]));
     const int32_t apron = (int32_t)ceilf((0.01f + 8.0f * sample_step) * m + 0.5f) + 1;
     const int32_t bias = ((apron + 3) / 4) * 4;
-    out_bias_g[0] = bias;
-    out_bias_g[1] = ((int32_t)dims[0] + 2 * bias + 3) / 4 + 1;
-    out_bias_g[2] = ((int32_t)dims[1] + 2 * bias + 3) / 4 + 1;
-    out_bias_g[3] = ((int32_t)dims[2] + 2 * bias + 3) / 4 + 1;
+    int32_t shift = 2;
+    for (;; shift++) {
+        const int64_t c = (int64_t)1 << shift;
+        const int64_t gx = ((int64_t)dims[0] + 2 * bias + c - 1) >> shift, gy = ((int64_t)dims[1] + 2 * bias + c - 1) >> shift,
+                      gz = ((int64_t)dims[2] + 2 * bias + c - 1) >> shift;
+        if (gx * gy * gz <= ORC_MAJ_CELLS_MAX) {
+            out[1] = (int32_t)gx;
+            out[2] = (int32_t)gy;
+            out[3] = (int32_t)gz;
+            break;
+        }
+    }
+    out[0] = bias;
+    out[4] = shift;
 }
 
-ORC_API void orc_build_majorants(const uint8_t *texels, const uint32_t dims[3], int32_t bias, int32_t gx, int32_t gy,
-                                 int32_t gz, uint8_t *out)
+ORC_API void orc_build_majorants(const uint8_t *texels, const uint32_t dims[3], int32_t bias, int32_t shift, int32_t gx,
+                                 int32_t gy, int32_t gz, uint8_t *out)
 {
     const int32_t nx = (int32_t)dims[0], ny = (int32_t)dims[1], nz = (int32_t)dims[2];
+    const int32_t C = 1 << shift;
 #pragma omp parallel for schedule(static)
-    for (int32_t bz = 0; bz < gz; bz++) {
-        for (int32_t by = 0; by < gy; by++) {
-            for (int32_t bx = 0; bx < gx; bx++) {
+    for (int32_t cz = 0; cz < gz; cz++) {
+        for (int32_t cy = 0; cy < gy; cy++) {
+            for (int32_t cx = 0; cx < gx; cx++) {
                 uint8_t m = 0;
-                for (int32_t z = 4 * bz - bias - 1; z <= 4 * bz - bias + 5; z++) {
+                for (int32_t z = C * cz - bias - 1; z <= C * cz - bias + C + 1; z++) {
                     const int32_t zc = clampi(z, 0, nz - 1);
-                    for (int32_t y = 4 * by - bias - 1; y <= 4 * by - bias + 5; y++) {
+                    for (int32_t y = C * cy - bias - 1; y <= C * cy - bias + C + 1; y++) {
                         const int32_t yc = clampi(y, 0, ny - 1);
-                        for (int32_t x = 4 * bx - bias - 1; x <= 4 * bx - bias + 5; x++) {
+                        for (int32_t x = C * cx - bias - 1; x <= C * cx - bias + C + 1; x++) {
                             const uint8_t v = texels[((size_t)zc * ny + yc) * nx + clampi(x, 0, nx - 1)];
                             m = v > m ? v : m;
                         }
                     }
                 }
-                out[((size_t)bz * gy + by) * gx + bx] = m;
+                out[((size_t)cz * gy + cy) * gx + cx] = m;
             }
         }
     }
@@ -400,17 +419,18 @@ static Event delta_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCount
     const float v[3] = { dir.x * c->density.sx, dir.y * c->density.sy, dir.z * c->density.sz };
     int32_t b[3], step[3];
     float tmax[3], tdelta[3];
+    const float edge = (float)(1 << c->maj_shift);
     for (int a = 0; a < 3; a++) {
         const int32_t cell = (int32_t)floorf(tp[a]) + c->maj_bias;
-        b[a] = cell >> 2;
+        b[a] = cell >> c->maj_shift;
         if (v[a] > 0.0f) {
             step[a] = 1;
-            tmax[a] = ((float)(((b[a] + 1) << 2) - c->maj_bias) - tp[a]) / v[a];
-            tdelta[a] = 4.0f / v[a];
+            tmax[a] = ((float)(((b[a] + 1) << c->maj_shift) - c->maj_bias) - tp[a]) / v[a];
+            tdelta[a] = edge / v[a];
         } else if (v[a] < 0.0f) {
             step[a] = -1;
-            tmax[a] = ((float)((b[a] << 2) - c->maj_bias) - tp[a]) / v[a];
-            tdelta[a] = 4.0f / -v[a];
+            tmax[a] = ((float)((b[a] << c->maj_shift) - c->maj_bias) - tp[a]) / v[a];
+            tdelta[a] = edge / -v[a];
         } else {
             step[a] = 0;
             tmax[a] = INFINITY;

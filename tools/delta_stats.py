@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Scheduler statistics of one DELTA launch on the benchmark scene (needs CT_STATS=1 in the environment)."""
+import os, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+assert os.environ.get("CT_STATS"), "run with CT_STATS=1"
+import torch  # noqa: F401
+import deepestscatter_amd as ds
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+est = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t = ds.CloudTracer(ds.make_procedural_cloud(512), width=1024, height=1024, estimator=est)
+t.render_accumulate(1, 32)
+s0, k0 = t.debug_stats(), t.counters()
+t.render_accumulate(33, S)
+s1, k1 = t.debug_stats(), t.counters()
+paths = k1["paths"] - k0["paths"]
+for n in ("regen_phases", "regen_lanes", "march_phases", "march_lanes", "scatter_phases", "scatter_lanes", "fetched_steps",
+          "fetched_zero_cells", "skipped_steps"):
+    print(f"{n:28s} {(s1[n] - s0[n]) / paths:10.3f} per sample")
+for n in ("density_lookups", "inscatter_lookups", "scatter_events"):
+    print(f"{n:28s} {(k1[n] - k0[n]) / paths:10.3f} per sample")

@@ -1257,12 +1257,12 @@ hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const fl
 // states the algorithm).  Same persistent wave scheduler.  The majorant grid (DevScene::maj_cells, cells
 // of 2^mc_shift texels, at most kMajCellsMax of them) is copied to LDS by every block, so the DDA that
 // carries a flight from cell to cell reads no memory; the "march" phase becomes a tracking visit:
-//     walk cells (up to kDeltaHops per visit): M == 0 -> cross; M > 0 -> draw dt = -log(1-u)/sigma_bar,
-//     and if it leaves the cell, cross (the exponential is memoryless);
-//     otherwise advance, load the footprint at p = fma(dir, t, origin) -- the visit's one global load --
-//     and accept the collision when u' * sigma_bar < sigma(p).
+//     current cell M == 0 -> cross into the next one; M > 0 -> draw dt = -log(1-u)/sigma_bar, and if it
+//     leaves the cell, cross (the exponential is memoryless); otherwise advance, load the footprint at
+//     p = fma(dir, t, origin) -- the visit's one global load -- and accept the collision when
+//     u' * sigma_bar < sigma(p).  (Several crossings per visit were tried: the lanes that keep crossing
+//     hold up the wave; one step per visit and bursts of 3 visits measured best.)
 // =============================================================================================
-constexpr uint32_t kDeltaHops = 8;
 constexpr int kDeltaThreads = 768;
 
 struct Dda {
@@ -1596,13 +1596,12 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             uint32_t burst = drained ? sc.tail_burst : sc.march_burst;
             for (;;) {
             if (state == ST_MARCH) {
+                // one step of the flight: cross into the next cell, or draw a tentative collision in this one
                 bool ended = false, collide = false;
                 float sigma_bar = 0.0f;
-                for (uint32_t hop = 0; hop < kDeltaHops; hop++) {
-                    if (!cell_in_grid(sc, dda)) {
-                        ended = true; // left the grid without a collision
-                        break;
-                    }
+                if (!cell_in_grid(sc, dda)) {
+                    ended = true; // left the grid without a collision
+                } else {
                     const uint32_t M = lds_maj[cell_index(sc, dda)];
                     if (M != 0u) {
                         sigma_bar = ((float)M * (1.0f / 255.0f)) * sc.density_multiplier;
@@ -1612,12 +1611,13 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                         if (dda.t + dt < t_exit) {
                             dda.t = dda.t + dt;
                             collide = true;
-                            break;
                         }
                     }
-                    dda_cross(dda, dir);
-                    if (STATS) {
-                        st_skip += 1;
+                    if (!collide) {
+                        dda_cross(dda, dir);
+                        if (STATS) {
+                            st_skip += 1;
+                        }
                     }
                 }
                 if (collide) {

@@ -48,9 +48,10 @@ def parse_args():
     ap.add_argument("--mode", type=int, default=0, help="0 totalRadiance (Mie multi-scatter + NEE)")
     ap.add_argument("--estimator", type=int, default=0, choices=(0, 1),
                     help="0 MARCH = the reference's free-flight sampler (the parity path, default); "
-                         "1 DELTA = Woodcock tracking over brick majorants (unbiased, not the reference's)")
+                         "1 DELTA = Woodcock tracking over majorant cells (unbiased, not the reference's)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-delta-leg", action="store_true", help="skip the DELTA-estimator run reported beside the headline")
     ap.add_argument("--simple-kernel", action="store_true", help="A/B: one thread per pixel, nested loops")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a box with one GPU)")
@@ -89,6 +90,33 @@ def cpu_baseline(tex, ins, width, height, mode, target_s):
         "sample": f"centred {win[2]-win[0]}x{win[3]-win[1]} window x {spp} spp of the same volume/camera ({dt:.1f} s)",
         "lookups_per_s": lookups / dt,
     }
+
+
+def delta_leg(ds, tex, W, H, mode, S, steps):
+    """The same workload with the DELTA estimator (Woodcock tracking, BASELINE.json north_star's algorithm; unbiased,
+    not the reference's sampler, so it cannot be the parity path -- DESIGN.md 4.2), reported beside the headline:
+    a second handle, one warm-up step, `steps` enqueued steps between two waits.  Not part of `value`."""
+    import torch
+    t = ds.CloudTracer(tex, width=W, height=H, mode=mode, estimator=1)
+    t.render_accumulate_async(1, S)
+    t.synchronize()
+    k0, (r0, _, l0) = t.counters(), t.kernel_time()
+    torch.zeros(1, device="cuda").add_(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        t.render_accumulate_async(1 + S * (i + 1), S)
+    t.synchronize()
+    dt = time.perf_counter() - t0
+    k1, (r1, _, l1) = t.counters(), t.kernel_time()
+    t.close()
+    lookups = (k1["density_lookups"] - k0["density_lookups"]) + (k1["inscatter_lookups"] - k0["inscatter_lookups"])
+    paths = k1["paths"] - k0["paths"]
+    alg = 8 * lookups + 16 * paths
+    return {"estimator": "DELTA (Woodcock tracking over LDS-resident majorant cells)", "value": W * H * S * steps / dt / 1e6,
+            "unit": "Msamples/s", "ms_per_step": dt / steps * 1e3, "kernel": "render_delta_kernel",
+            "avg_launch_ms": (r1 - r0) / max(l1 - l0, 1), "lookups_per_sample": lookups / max(paths, 1),
+            "roofline_frac": alg / ((r1 - r0) * 1e-3) / 1e9 / HBM_PEAK_GBS if r1 > r0 else 0.0}
 
 
 def main():
@@ -238,7 +266,7 @@ def main():
                         f"(BASELINE.json configs[{2 if world == 1 else 3}]: a 1024 spp job is {1024 / max(S, 1):g} such steps), "
                         f"mode {('totalRadiance','multipleScatterSunRadiance','singleScatterSunRadiance')[args.mode]} "
                         "(Mie multi-scatter + NEE), estimator "
-                        f"{('MARCH (reference-faithful)', 'DELTA (Woodcock, brick majorants)')[args.estimator]}, max_depth 2000",
+                        f"{('MARCH (reference-faithful)', 'DELTA (Woodcock, LDS-resident majorant cells)')[args.estimator]}, max_depth 2000",
             "volume": args.volume, "width": W, "height": H, "spp_per_step": S,
             "parallelism": f"pixel-tile shard x{world}" + (" + RCCL reduce of the radiance buffer" if world > 1 else ""),
             "pipelined_steps": not args.sync_steps,
@@ -247,6 +275,8 @@ def main():
         "setup_s": setup_s,
     }
 
+    if rank == 0 and world == 1 and args.estimator == 0 and not args.simple_kernel and not args.no_delta_leg:
+        out["delta_estimator"] = delta_leg(ds, tex, W, H, args.mode, S, max(args.steps, 1))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ins = tr.inscatter()
         out["cpu_baseline"] = cpu_baseline(tex, ins, W, H, args.mode, args.cpu_seconds)

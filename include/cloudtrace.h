@@ -62,7 +62,7 @@ typedef enum CtMode {
 } CtMode;
 
 /* Free-flight sampler. MARCH is the reference's estimator (cloud.cuh:77-114);
- * DELTA is Woodcock tracking over per-brick majorants (BASELINE.json north_star). */
+ * DELTA is Woodcock tracking over a grid of majorant cells (BASELINE.json north_star). */
 typedef enum CtEstimator {
     CT_EST_MARCH = 0,
     CT_EST_DELTA = 1

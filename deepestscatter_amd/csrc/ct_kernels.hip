@@ -1296,11 +1296,13 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
     const float edge = (float)(1 << sc.mc_shift);
     auto axis = [&](int32_t B, float TP, float V, float &TMAX, float &TDELTA) {
         if (V > 0.0f) {
-            TMAX = ((float)(((B + 1) << sc.mc_shift) - sc.brick_bias) - TP) / V;
-            TDELTA = edge / V;
+            const float inv = 1.0f / V; // one division per axis, as in the oracle
+            TMAX = ((float)(((B + 1) << sc.mc_shift) - sc.brick_bias) - TP) * inv;
+            TDELTA = edge * inv;
         } else if (V < 0.0f) {
-            TMAX = ((float)((B << sc.mc_shift) - sc.brick_bias) - TP) / V;
-            TDELTA = edge / -V;
+            const float inv = 1.0f / V;
+            TMAX = ((float)((B << sc.mc_shift) - sc.brick_bias) - TP) * inv;
+            TDELTA = edge * -inv;
         } else {
             TMAX = inf;
             TDELTA = inf;
@@ -1400,7 +1402,7 @@ hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primar
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6))) void render_delta_kernel(DevScene sc, BatchArgs ba)
 {
-    // 24 KiB of Mie tables + 40 KiB of majorants per block of 768 threads: two blocks per CU, 6 waves per SIMD
+    // 24 KiB of Mie tables + 40 KiB of majorants + 2 KiB per block of 768 threads: two blocks per CU, 6 waves per SIMD
     __shared__ MieLds lds;
     __shared__ uint32_t maj_words[kMajCellsMax / 4];
     {
@@ -1411,6 +1413,12 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         }
     }
     const uint8_t *lds_maj = (const uint8_t *)maj_words;
+    // sigma_bar and 1/sigma_bar of every majorant value (delta_flight in the oracle computes the same two floats)
+    __shared__ float2 sigma_table[256];
+    if (threadIdx.x < 256u) {
+        const float sb = ((float)threadIdx.x * (1.0f / 255.0f)) * sc.density_multiplier;
+        sigma_table[threadIdx.x] = make_float2(sb, 1.0f / sb);
+    }
     load_tables(sc, lds);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -1604,9 +1612,10 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                 } else {
                     const uint32_t M = lds_maj[cell_index(sc, dda)];
                     if (M != 0u) {
-                        sigma_bar = ((float)M * (1.0f / 255.0f)) * sc.density_multiplier;
+                        const float2 sb = sigma_table[M];
+                        sigma_bar = sb.x;
                         const float u = u24_to_float(lcg24(seed));
-                        const float dt = -logf_above_one(1.0f - u) / sigma_bar;
+                        const float dt = -logf_above_one(1.0f - u) * sb.y;
                         const float t_exit = fminf(fminf(dda.tmax.x, dda.tmax.y), dda.tmax.z);
                         if (dda.t + dt < t_exit) {
                             dda.t = dda.t + dt;

@@ -353,8 +353,8 @@ static Event next_scattering_event(const Ctx *c, float optical_distance, v3 pos,
  *   sigma_bar = (float)M * (1/255.f) * densityMultiplier.
  *
  *   flight from pos along dir:  tp = pos*scale - 0.5 (texel coordinates), v = dir*scale;
- *   3-D DDA over the cells in the ray parameter t (box units): tmax_a = (bound_a - tp_a)/v_a,
- *   tdelta_a = C/|v_a|.  In a cell with M > 0:  dt = -log(1 - rnd)/sigma_bar; if t + dt reaches
+ *   3-D DDA over the cells in the ray parameter t (box units): tmax_a = (bound_a - tp_a)*(1/v_a),
+ *   tdelta_a = C*|1/v_a|.  In a cell with M > 0:  dt = -log(1 - rnd)*(1/sigma_bar); if t + dt reaches
  *   the cell's exit the flight moves on to the next cell (the exponential is memoryless);
  *   otherwise t += dt, p = fma(dir, t, pos), sigma = sample(p) [one density lookup], and the
  *   collision is real when rnd * sigma_bar < sigma.  Leaving the grid ends the flight without a
@@ -424,13 +424,15 @@ static Event delta_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCount
         const int32_t cell = (int32_t)floorf(tp[a]) + c->maj_bias;
         b[a] = cell >> c->maj_shift;
         if (v[a] > 0.0f) {
+            const float inv = 1.0f / v[a]; /* one division per axis; the products below are what the kernel computes */
             step[a] = 1;
-            tmax[a] = ((float)(((b[a] + 1) << c->maj_shift) - c->maj_bias) - tp[a]) / v[a];
-            tdelta[a] = edge / v[a];
+            tmax[a] = ((float)(((b[a] + 1) << c->maj_shift) - c->maj_bias) - tp[a]) * inv;
+            tdelta[a] = edge * inv;
         } else if (v[a] < 0.0f) {
+            const float inv = 1.0f / v[a];
             step[a] = -1;
-            tmax[a] = ((float)((b[a] << c->maj_shift) - c->maj_bias) - tp[a]) / v[a];
-            tdelta[a] = edge / -v[a];
+            tmax[a] = ((float)((b[a] << c->maj_shift) - c->maj_bias) - tp[a]) * inv;
+            tdelta[a] = edge * -inv;
         } else {
             step[a] = 0;
             tmax[a] = INFINITY;
@@ -447,9 +449,10 @@ static Event delta_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCount
         const uint8_t M = c->maj[((size_t)b[2] * c->maj_gy + b[1]) * c->maj_gx + b[0]];
         if (M != 0) {
             const float sigma_bar = ((float)M * (1.0f / 255.0f)) * c->density_multiplier;
+            const float mean_free = 1.0f / sigma_bar; /* (the kernel keeps both in a 256-entry LDS table) */
             for (;;) {
                 const float u = orc_rnd(seed);
-                const float dt = -ct_logf(1.0f - u) / sigma_bar;
+                const float dt = -ct_logf(1.0f - u) * mean_free;
                 if (t + dt >= t_exit) {
                     break;
                 }

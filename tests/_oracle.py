@@ -98,8 +98,7 @@ def lib(fast: bool = False):
         return _LIB[key]
     name = "libct_oracle_fma.so" if key == "fma" else "libct_oracle.so"
     path = ORACLE_DIR / name
-    if not path.exists():
-        build(force=True)
+    build(force=not path.exists())   # also rebuilds a library older than its source before it is loaded
     L = C.CDLL(str(path))
     f32p = C.POINTER(C.c_float)
     L.orc_tea4.restype = C.c_uint32

@@ -3,13 +3,14 @@
 
     python tools/per_dispatch.py gpurun_out/prof_r01n render_persistent
 """
-import csv, glob, sys
+import csv, glob, os, sys
 d, name = sys.argv[1], sys.argv[2]
-f = glob.glob(d + "/trace/*/*_kernel_trace.csv")[0]
+f = max(glob.glob(d + "/trace/*/*_kernel_trace.csv"), key=os.path.getmtime)   # (a merged directory may hold older runs)
 rows = [r for r in csv.DictReader(open(f)) if name in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 print("duration_ms", [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 2) for r in rows])
-for p in sorted(glob.glob(d + "/pmc*/*/*_counter_collection.csv")):
+for pd in sorted(glob.glob(d + "/pmc*/")):
+    p = max(glob.glob(pd + "*/*_counter_collection.csv"), key=os.path.getmtime)
     by = {}
     for r in csv.DictReader(open(p)):
         if name in r["Kernel_Name"]:

@@ -1250,9 +1250,11 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
     uint64_t cap = std::min<uint64_t>((8ull << 30) / (stride * sizeof(float4)), 0xffffffffull / stride);
     cap = std::max<uint64_t>(std::min<uint64_t>(cap, 0xffffull), 1);
     uint32_t done = 0;
+    // job lists are built for the size of the call's batches, not for the remainder that follows the short
+    // cost-measuring launch (the next call of the same size would rebuild them)
+    h->jobs_hint = (uint32_t)std::min<uint64_t>(cap, count);
     while (done < count) {
         uint32_t S = (uint32_t)std::min<uint64_t>(cap, count - done);
-        h->jobs_hint = S;
         int rc;
         if (!simple && !h->order_tuned) {
             // the first launch of a pose measures the job costs (two atomics per path, jobs in image

@@ -339,13 +339,15 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.scatter_den = 1;
     d.scatter_min = 1;
     // measured (profiles/README.md, burst sweep): 1207 Msamples/s without bursts, 1453 with 8/32/32
+    // (re-swept on the final kernel, 512 spp per launch: burst_scatter 48 -> 40 is worth +3 %, 2871 -> 2963)
     d.march_burst = 8;
-    d.burst_scatter = 48;
+    d.burst_scatter = 40;
     d.burst_idle = 32;
     if (s->estimator == CT_EST_DELTA) {
         // a tracking visit ends in a real collision 6 times out of 10: short bursts and an early refill
         // (sweep at 512^3/1024^2: 8/16 -> 2300 Msamples/s, 1/16 -> 2700, 1/4 -> 2870, 3/4 -> 3460)
         d.march_burst = 3;
+        d.burst_scatter = 48;
         d.regen_min = 4;
     }
     // measured (profiles/README.md): regional queues raise the L2 hit rate from 67 % to 77 % but not

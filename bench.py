@@ -96,13 +96,10 @@ def delta_leg(ds, tex, W, H, mode, S, steps):
     """The same workload with the DELTA estimator (Woodcock tracking, BASELINE.json north_star's algorithm; unbiased,
     not the reference's sampler, so it cannot be the parity path -- DESIGN.md 4.2), reported beside the headline:
     a second handle, one warm-up step, `steps` enqueued steps between two waits.  Not part of `value`."""
-    import torch
     t = ds.CloudTracer(tex, width=W, height=H, mode=mode, estimator=1)
     t.render_accumulate_async(1, S)
     t.synchronize()
     k0, (r0, _, l0) = t.counters(), t.kernel_time()
-    torch.zeros(1, device="cuda").add_(1)
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         t.render_accumulate_async(1 + S * (i + 1), S)
@@ -187,12 +184,6 @@ def main():
     k0 = tr.counters()
     r0, a0, l0 = tr.kernel_time()
     fence()
-    # The first GPU submission after the device-wide synchronize above was seen to start 20-30 ms late in
-    # most runs (first timed step 130-139 ms instead of 109, every kernel duration unchanged, gone under
-    # rocprofv3); a one-element torch op absorbs that wake-up before the clock starts.  It does no work of
-    # the benchmark, and the timed region is still bracketed by a synchronize on both sides.
-    torch.zeros(1, device="cuda").add_(1)
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     step_marks = []
     for _ in range(args.steps):

@@ -31,8 +31,6 @@ t.render_accumulate_async(1, S)
 t.synchronize()
 k0 = t.counters()
 kt0 = t.kernel_time()
-torch.zeros(1, device="cuda").add_(1)   # see bench.py: absorbs the late first submission after a device-wide wait
-torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(a.steps):
     t.render_accumulate_async(1 + S * (i + 1), S)

@@ -317,7 +317,7 @@ class CloudTracer:
         check(self.L.ct_debug_stats(self.h, _p(out)), self.h)
         names = ["regen_phases", "regen_lanes", "march_phases", "march_lanes", "scatter_phases", "scatter_lanes",
                  "fetched_steps", "fetched_zero_cells", "skipped_steps", "zero_cells_nonfree_brick",
-                 "zero_cells_free_brick_d1", "skip_loop_wave_iterations", "fetched_steps_first_flight", "waves",
+                 "zero_cells_free_brick_d1", "skip_loop_wave_iterations", "nee_footprints_reused", "waves",
                  "stolen_jobs", "max_scheduler_visits_of_a_wave"]
         d = {n: int(v) for n, v in zip(names, out)}
         # waves by the time they ended (5 ms bins from their own start), and by how long they kept

@@ -424,6 +424,10 @@ static int create_impl(const CtScene *s, CtHandle h)
         return fail(h, CT_E_INVAL, "volume too large for 32-bit brick indices");
     }
     d.brick_bias = bbias;
+    d.nee_cache = (bgx * bgy * bgz < (1ll << 25)) ? 1u : 0u;
+    if (const char *e = getenv("CT_NEE_CACHE")) {
+        d.nee_cache = (atoi(e) != 0 && d.nee_cache) ? 1u : 0u;
+    }
     d.brick_gx = (int32_t)bgx;
     d.brick_gxy = (int32_t)(bgx * bgy);
     d.brick_gy = (int32_t)bgy;

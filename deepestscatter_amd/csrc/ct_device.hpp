@@ -111,6 +111,7 @@ struct DevScene {
     uint32_t burst_scatter; // ... this many lanes wait for the scatter phase, or ...
     uint32_t burst_idle;   // ... this many lanes are idle)
     uint32_t tail_burst;   // march steps per visit once the job queue is empty
+    uint32_t nee_cache;    // 1 = fetch_cell_cached may reuse a lane's last shadow-volume footprint (fewer than 2^25 bricks)
     uint32_t hint_period;  // scheduler visits between two looks at the job counter (power of two, 0 = never)
     uint32_t burst_march_min; // a burst also ends when fewer lanes than this still march (>= 1)
     uint32_t scatter_num, scatter_den; // run the scatter phase when nb * den > nm * num ...
@@ -276,6 +277,31 @@ CT_DEV uint2 fetch_cell_in_grid(const DevScene &sc, const uint8_t *bricks, f3 p,
     const int32_t iy = min(max(floor_to_int(y), lo), 4 * sc.brick_gy - 1 + lo);
     const int32_t iz = min(max(floor_to_int(z), lo), 4 * sc.brick_gz - 1 + lo);
     return load_footprint_meta(sc, bricks, ix, iy, iz, meta);
+}
+
+// A lane's own one-entry cache in front of fetch_cell: consecutive scatter events of a path are about a mean
+// free path apart, which at the reference's settings is about a texel, so the shadow-volume footprint of the next
+// event is often the one just read.  `key` = the footprint's byte offset in the brick array (0xffffffff = empty);
+// the volumes are immutable, so an entry never goes stale and may outlive the path that loaded it.
+CT_DEV uint2 fetch_cell_cached(const DevScene &sc, const uint8_t *bricks, f3 p, uint32_t &key, uint2 &cached, bool &reused)
+{
+    const float fx = fmaf(p.x, sc.sx, -0.5f), fy = fmaf(p.y, sc.sy, -0.5f), fz = fmaf(p.z, sc.sz, -0.5f);
+    const uint32_t x = (uint32_t)(floor_to_int(fx) + sc.brick_bias), y = (uint32_t)(floor_to_int(fy) + sc.brick_bias),
+                   z = (uint32_t)(floor_to_int(fz) + sc.brick_bias);
+    const uint32_t brick = __umul24(z >> 2, (uint32_t)sc.brick_gxy) + __umul24(y >> 2, (uint32_t)sc.brick_gx) + (x >> 2);
+    const uint32_t local = __umul24(z & 3u, 25u) + __umul24(y & 3u, 5u) + (x & 3u);
+    const uint32_t off = (brick << 7) | local;   // unique while there are fewer than 2^25 bricks: DevScene::nee_cache
+    reused = sc.nee_cache != 0u && off == key;
+    if (!reused) {
+        const uint8_t *q = bricks + (((size_t)brick << 7) | local);
+        uint2 a, c;
+        __builtin_memcpy(&a, q, 8);
+        __builtin_memcpy(&c, q + 25, 8);
+        cached.x = __builtin_amdgcn_perm(a.y, a.x, 0x06050100u);
+        cached.y = __builtin_amdgcn_perm(c.y, c.x, 0x06050100u);
+        key = off;
+    }
+    return cached;
 }
 
 CT_DEV uint2 fetch_cell_m(const DevScene &sc, f3 p, uint32_t &meta)

@@ -571,8 +571,11 @@ CT_DEV NeeLoads in_scattering_issue(const DevScene &sc, f3 pos, f3 dir, bool cho
     return n;
 }
 
-// The same with the chopped table in LDS (MARCH kernel); the un-chopped one (first bounce) stays global.
-CT_DEV NeeLoads in_scattering_issue_lds(const DevScene &sc, const float *lds_chopped, f3 pos, f3 dir, bool chopped)
+// The same with the chopped table in LDS and the lane's one-entry footprint cache (MARCH kernel; in the DELTA kernel,
+// which is bound by instruction issue at its register limit, the cache cost 2 %); the un-chopped table (first bounce)
+// stays global.
+CT_DEV NeeLoads in_scattering_issue_lds(const DevScene &sc, const float *lds_chopped, f3 pos, f3 dir, bool chopped,
+                                        uint32_t &nee_key, uint2 &nee_cell, bool &reused)
 {
     NeeLoads n;
     const float cos_light = dot3(mk3(sc.nlx, sc.nly, sc.nlz), dir);
@@ -589,8 +592,7 @@ CT_DEV NeeLoads in_scattering_issue_lds(const DevScene &sc, const float *lds_cho
     n.a = (i > kMieN - 2) ? pair.y : pair.x;
     n.b = (i < 0) ? pair.x : pair.y;
     n.w = fract_(x);
-    uint32_t meta_unused;
-    n.cell = fetch_cell(sc, sc.ibricks, pos, meta_unused);
+    n.cell = fetch_cell_cached(sc, sc.ibricks, pos, nee_key, nee_cell, reused);
     return n;
 }
 
@@ -760,6 +762,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
     uint32_t c_dl = 0, c_il = 0, c_cap = 0; // per-lane tallies
+    uint32_t nee_key = 0xffffffffu;         // fetch_cell_cached: this lane's last shadow-volume footprint
+    uint2 nee_cell = make_uint2(0u, 0u);
     // scheduler diagnostics (STATS builds only), see ct_debug_stats
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0, st_iters = 0, st_first = 0;
@@ -927,7 +931,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 // isInBox(scatterPos), cloudRadianceMaterials.cu:49-52
                 if (dfree != 0u || in_box(sc, pos)) {
                     const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
-                    const NeeLoads nee = in_scattering_issue_lds(sc, lds.chopped, pos, dir, chopped);
+                    bool nee_reused;
+                    const NeeLoads nee = in_scattering_issue_lds(sc, lds.chopped, pos, dir, chopped, nee_key, nee_cell, nee_reused);
+                    if (STATS) {
+                        st_first += nee_reused ? 1u : 0u;
+                    }
                     c_il += 1;
                     work += 4u;
                     bool go = (MODE != 2);
@@ -996,7 +1004,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 c_dl += 1;
                 work += 1u;
                 if (STATS) {
-                    st_first += (depth <= 1u) ? 1u : 0u;
                     st_fetch += 1;
                     st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
                     st_zero_d0 += ((cell.x | cell.y) == 0u && dfree == 0u) ? 1u : 0u;

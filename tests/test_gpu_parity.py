@@ -851,7 +851,7 @@ def test_scheduler_knobs_never_change_a_result(monkeypatch):
         {"CT_XCD_QUEUES": "1"}, {"CT_XCD_QUEUES": "1", "CT_XCD_REGIONS": "8", "CT_SHARED_DEPTH": "4"},
         {"CT_BLOCKS_PER_CU": "1"}, {"CT_BLOCKS_PER_CU": "3"},
         {"CT_NO_ADVANCE": "1"}, {"CT_CONTINUATION": "0"}, {"CT_HINT_PERIOD": "1"}, {"CT_HINT_PERIOD": "0"},
-        {"CT_TAIL_BURST": "1"}, {"CT_BURST_MARCH_MIN": "20"},
+        {"CT_TAIL_BURST": "1"}, {"CT_BURST_MARCH_MIN": "20"}, {"CT_NEE_CACHE": "0"},
     ]
     for env in settings:
         for k, v in env.items():

@@ -32,7 +32,7 @@ struct CtHandle_ {
     bool camera_set = false;
 
     // device memory
-    uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr, *d_majorant = nullptr, *d_maj_cells = nullptr;
+    uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr, *d_majorant = nullptr, *d_maj_cells = nullptr, *d_maj_codes = nullptr;
     uint8_t *d_dbricks = nullptr, *d_ibricks = nullptr, *d_mbricks = nullptr;
     uint8_t *d_pyramid = nullptr;     // density mip pyramid, built on first use (ct_collect_descriptors)
     MipPyramid pyramid{};
@@ -235,7 +235,7 @@ static void release(CtHandle h)
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->slots[0].queue, h->slots[1].queue, h->slots[0].cont, h->slots[1].cont, h->d_cont_count, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->slots[0].queue, h->slots[1].queue, h->slots[0].cont, h->slots[1].cont, h->d_cont_count, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
         if (p) {
@@ -493,9 +493,12 @@ static int create_impl(const CtScene *s, CtHandle h)
         const size_t cells = (size_t)(cgx * cgy * cgz);
         HIPCHK(h, dmalloc(&h->d_maj_cells, (cells + 3) & ~(size_t)3)); // the kernel copies whole words
         HIPCHK(h, hipMemsetAsync(h->d_maj_cells, 0, (cells + 3) & ~(size_t)3, h->stream));
+        HIPCHK(h, dmalloc(&h->d_maj_codes, (cells + 3) & ~(size_t)3));
+        HIPCHK(h, hipMemsetAsync(h->d_maj_codes, 0, (cells + 3) & ~(size_t)3, h->stream));
         HIPCHK(h, launch_majorant_cells(h->d_density, nx, ny, nz, bbias, shift, (int)cgx, (int)cgy, (int)cgz, h->d_maj_cells,
-                                        h->stream));
+                                        h->d_maj_codes, h->stream));
         d.maj_cells = h->d_maj_cells;
+        d.maj_codes = h->d_maj_codes;
         d.mc_shift = shift;
         d.mc_gx = (int32_t)cgx;
         d.mc_gy = (int32_t)cgy;

@@ -84,6 +84,7 @@ struct DevScene {
     // has at most kMajCellsMax cells, so that every block keeps the whole grid in LDS and a flight crosses cells
     // without touching memory (oracle/ct_oracle.c, DELTA header: same grid, same majorants).
     const uint8_t *maj_cells;
+    const uint8_t *maj_codes;   // per cell q = min(3, 4*min/max) of its texels: texel value (q*M) >> 2 bounds the cell from below
     int32_t mc_shift, mc_gx, mc_gy, mc_gz;
     int32_t m_bias_x;        // x bias of the 3-texel brick columns (multiple of 3)
     int32_t m_gx, m_gxy;     // bricks per row / per slice of mbricks (y and z use brick_gy/gz, brick_bias)

@@ -1366,36 +1366,44 @@ __global__ __launch_bounds__(256) void primary_advance_delta_kernel(DevScene sc,
     advance[4 * p + 3] = make_float4(__int_as_float(d.bz), 0.f, 0.f, 0.f);
 }
 
-// Majorant of every cell of the DELTA grid: the max of the texels [lo-1, lo+C+1]^3 (clamped), one block
-// per cell (orc_build_majorants in the oracle).
+// Majorant of every cell of the DELTA grid: the max of the texels [lo-1, lo+C+1]^3 (clamped), and the 2-bit code
+// of their min (q = min(3, 4*min/max)); one block per cell (orc_build_majorants in the oracle).
 __global__ __launch_bounds__(256) void majorant_cells_kernel(const uint8_t *__restrict__ texels, int nx, int ny, int nz, int bias,
-                                                             int shift, int gx, int gy, uint8_t *__restrict__ out)
+                                                             int shift, int gx, int gy, uint8_t *__restrict__ out,
+                                                             uint8_t *__restrict__ out_codes)
 {
     const int cx = blockIdx.x, cy = blockIdx.y, cz = blockIdx.z;
     const int C = 1 << shift, w = C + 3;
     const int x0 = C * cx - bias - 1, y0 = C * cy - bias - 1, z0 = C * cz - bias - 1;
-    uint32_t m = 0;
+    uint32_t m = 0, lo = 255;
     for (int i = threadIdx.x; i < w * w * w; i += 256) {
         const int lx = i % w, ly = (i / w) % w, lz = i / (w * w);
         const int x = min(max(x0 + lx, 0), nx - 1), y = min(max(y0 + ly, 0), ny - 1), z = min(max(z0 + lz, 0), nz - 1);
-        m = max(m, (uint32_t)texels[((size_t)z * ny + y) * nx + x]);
+        const uint32_t v = texels[((size_t)z * ny + y) * nx + x];
+        m = max(m, v);
+        lo = min(lo, v);
     }
-    __shared__ uint32_t red;
+    __shared__ uint32_t red_max, red_min;
     if (threadIdx.x == 0) {
-        red = 0;
+        red_max = 0;
+        red_min = 255;
     }
     __syncthreads();
-    atomicMax(&red, m);
+    atomicMax(&red_max, m);
+    atomicMin(&red_min, lo);
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[((size_t)cz * gy + cy) * gx + cx] = (uint8_t)red;
+        const size_t cell = ((size_t)cz * gy + cy) * gx + cx;
+        out[cell] = (uint8_t)red_max;
+        out_codes[cell] = (uint8_t)(red_max ? min(3u, 4u * red_min / red_max) : 0u);
     }
 }
 
 hipError_t launch_majorant_cells(const uint8_t *texels, int nx, int ny, int nz, int bias, int shift, int gx, int gy, int gz,
-                                 uint8_t *out, hipStream_t stream)
+                                 uint8_t *out, uint8_t *out_codes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(majorant_cells_kernel, dim3(gx, gy, gz), dim3(256), 0, stream, texels, nx, ny, nz, bias, shift, gx, gy, out);
+    hipLaunchKernelGGL(majorant_cells_kernel, dim3(gx, gy, gz), dim3(256), 0, stream, texels, nx, ny, nz, bias, shift, gx, gy, out,
+                       out_codes);
     return hipGetLastError();
 }
 
@@ -1409,7 +1417,8 @@ hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primar
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6))) void render_delta_kernel(DevScene sc, BatchArgs ba)
 {
-    // 24 KiB of Mie tables + 40 KiB of majorants + 2 KiB per block of 768 threads: two blocks per CU, 6 waves per SIMD
+    // 24 KiB of Mie tables + 40 KiB of majorants + 10 KiB of lower-bound codes + 2 KiB per block of 768 threads:
+    // two blocks per CU, 6 waves per SIMD
     __shared__ MieLds lds;
     __shared__ uint32_t maj_words[kMajCellsMax / 4];
     {
@@ -1420,6 +1429,16 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         }
     }
     const uint8_t *lds_maj = (const uint8_t *)maj_words;
+    // the cells' lower-bound codes, 2 bits each (the array in memory holds one per byte, padded to whole words)
+    __shared__ uint8_t lds_codes[kMajCellsMax / 4];
+    {
+        const uint32_t words = ((uint32_t)(sc.mc_gx * sc.mc_gy * sc.mc_gz) + 3u) >> 2;
+        const uint32_t *src = (const uint32_t *)sc.maj_codes;
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
+            const uint32_t w = src[i];
+            lds_codes[i] = (uint8_t)((w & 3u) | ((w >> 6) & 0xcu) | ((w >> 12) & 0x30u) | ((w >> 18) & 0xc0u));
+        }
+    }
     // sigma_bar and 1/sigma_bar of every majorant value (delta_flight in the oracle computes the same two floats)
     __shared__ float2 sigma_table[256];
     if (threadIdx.x < 256u) {
@@ -1613,12 +1632,15 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             if (state == ST_MARCH) {
                 // one step of the flight: cross into the next cell, or draw a tentative collision in this one
                 bool ended = false, collide = false;
-                float sigma_bar = 0.0f;
+                float sigma_bar = 0.0f, sigma_low = 0.0f;
                 if (!cell_in_grid(sc, dda)) {
                     ended = true; // left the grid without a collision
                 } else {
-                    const uint32_t M = lds_maj[cell_index(sc, dda)];
+                    const uint32_t ci = cell_index(sc, dda);
+                    const uint32_t M = lds_maj[ci];
                     if (M != 0u) {
+                        const uint32_t q = ((uint32_t)lds_codes[ci >> 2] >> ((ci & 3u) * 2u)) & 3u;
+                        sigma_low = sigma_table[(q * M) >> 2].x;
                         const float2 sb = sigma_table[M];
                         sigma_bar = sb.x;
                         const float u = u24_to_float(lcg24(seed));
@@ -1638,16 +1660,20 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                 }
                 if (collide) {
                     const f3 p = mk3(fmaf(dir.x, dda.t, dda.org.x), fmaf(dir.y, dda.t, dda.org.y), fmaf(dir.z, dda.t, dda.org.z));
-                    uint32_t meta_unused;
-                    const uint2 cell = fetch_cell_in_grid(sc, sc.dbricks, p, meta_unused);
-                    c_dl += 1;
-                    if (STATS) {
-                        st_fetch += 1;
-                        st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
-                    }
-                    const float sigma = filter_at(sc, cell, p) * sc.density_multiplier;
                     const float z = u24_to_float(lcg24(seed));
-                    if (z * sigma_bar < sigma) {
+                    // sigma(p) >= sigma_low throughout the cell: below it the collision is real without a lookup
+                    bool real = z * sigma_bar < sigma_low;
+                    if (!real) {
+                        uint32_t meta_unused;
+                        const uint2 cell = fetch_cell_in_grid(sc, sc.dbricks, p, meta_unused);
+                        c_dl += 1;
+                        if (STATS) {
+                            st_fetch += 1;
+                            st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
+                        }
+                        real = z * sigma_bar < filter_at(sc, cell, p) * sc.density_multiplier;
+                    }
+                    if (real) {
                         pos = p;
                         if (in_box(sc, pos)) {
                             state = ST_BOUNCE;

@@ -48,6 +48,7 @@ class OrcScene(C.Structure):
         ("maj_gy", C.c_int32),
         ("maj_gz", C.c_int32),
         ("maj_shift", C.c_int32),
+        ("maj_codes", C.c_void_p),
     ]
 
 
@@ -122,7 +123,7 @@ def lib(fast: bool = False):
     L.orc_point_radiance_launch.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.POINTER(OrcCounters), C.c_int32]
     L.orc_majorant_grid.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
-    L.orc_build_majorants.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.orc_build_majorants.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.orc_generate_scatter_samples.argtypes = [C.POINTER(OrcScene), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.orc_collect_descriptors.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.orc_collect_descriptors.restype = None
@@ -238,8 +239,11 @@ class Oracle:
             self.L.orc_majorant_grid(_ptr(dims), self.sample_step, _ptr(grid))
             bias, gx, gy, gz, shift = (int(v) for v in grid)
             self.majorant = np.empty((gz, gy, gx), np.uint8)
-            self.L.orc_build_majorants(_ptr(self.density), _ptr(dims), bias, shift, gx, gy, gz, _ptr(self.majorant))
+            self.majorant_codes = np.empty((gz, gy, gx), np.uint8)
+            self.L.orc_build_majorants(_ptr(self.density), _ptr(dims), bias, shift, gx, gy, gz, _ptr(self.majorant),
+                                       _ptr(self.majorant_codes))
             s.majorant = self.majorant.ctypes.data
+            s.maj_codes = self.majorant_codes.ctypes.data
             s.maj_bias, s.maj_gx, s.maj_gy, s.maj_gz, s.maj_shift = bias, gx, gy, gz, shift
         self.scene = s
         if self.inscatter is None:

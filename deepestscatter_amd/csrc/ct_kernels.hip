@@ -2118,7 +2118,21 @@ __global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__re
         return;
     }
     float4 mu = mean[pix], var = m2[pix];
-    for (uint32_t s = 0; s < S; s++) {
+    // eight loads in flight per thread: a shard of an 8-GPU job has few pixels and many subframes, and one load
+    // per trip round the recurrence left it waiting for memory (3.6 ms for 131 k pixels x 4096 subframes, 2.5 now; sixteen are no better)
+    uint32_t s = 0;
+    for (; s + 8 <= S; s += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            v[k] = frames[(size_t)(s + k) * frame_stride + e];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            welford(mu, var, v[k], first_subframe + s + k);
+        }
+    }
+    for (; s < S; s++) {
         welford(mu, var, frames[(size_t)s * frame_stride + e], first_subframe + s);
     }
     mean[pix] = mu;

@@ -731,6 +731,32 @@ def test_north_star_parity_after_1024_spp_on_a_window():
     tr.close()
 
 
+@pytest.mark.parametrize("n,size,spp", [(512, 1024, 128), (144, 320, 24)])
+def test_delta_estimator_on_a_window_with_coarse_majorant_cells(n, size, spp):
+    """The DELTA estimator where its majorant grid has to coarsen to stay in LDS: 16-texel cells at 512^3 (the
+    benchmark scene, rendered the way bench.py's DELTA leg does: enqueued batches with path continuation), 8-texel
+    cells at 144^3.  The oracle renders a 16x16 window in the body of the cloud; mean and M2 must be bit-identical
+    (the small volumes of the other DELTA tests all have 4-texel cells)."""
+    tex = ds.make_procedural_cloud(n)
+    w = h = size
+    tr = ds.CloudTracer(tex, width=w, height=h, estimator=1)
+    half = spp // 2
+    tr.render_accumulate_async(1, half)
+    tr.render_accumulate_async(1 + half, spp - half)
+    tr.synchronize()
+    mean, m2 = tr.mean(), tr.m2()
+    orc = O.Oracle(tex, w, h, fast=True, estimator=1, inscatter=tr.inscatter())
+    assert orc.scene.maj_shift == (4 if n == 512 else 3)
+    x0, y0 = int(w * 0.49), int(h * 0.51)
+    win = (x0, y0, x0 + 16, y0 + 16)
+    ref_mean, ref_m2 = orc.render(spp, window=win)
+    got, ref = mean[y0:y0 + 16, x0:x0 + 16], ref_mean[y0:y0 + 16, x0:x0 + 16]
+    assert ref[..., 0].mean() > 0.3                     # the window is inside the cloud
+    assert np.array_equal(got, ref)
+    assert np.array_equal(m2[y0:y0 + 16, x0:x0 + 16], ref_m2[y0:y0 + 16, x0:x0 + 16])
+    tr.close()
+
+
 def _random_scene(rng):
     dims = tuple(int(v) for v in rng.integers(5, 41, 3))
     nz, ny, nx = dims[::-1]

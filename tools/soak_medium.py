@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Soak run at medium sizes: non-cubic procedural-like volumes of 48..160 texels per axis, frames of
+"""Soak run at medium sizes: non-cubic procedural-like volumes of 48..160 texels per axis (both estimators; at these
+sizes DELTA's majorant cells are 4 or 8 texels wide), frames of
 200..640 pixels, a random oracle window; HIP path (enqueued batches) vs oracle bit for bit on the window,
 plus counter identities on the whole frame.  python tools/soak_medium.py <seed> <cases>"""
 import sys
@@ -21,7 +22,7 @@ for case in range(cases):
     z0, y0, x0 = ((n - nz) // 2, (n - ny) // 2, (n - nx) // 2)
     tex = np.ascontiguousarray(cube[z0:z0 + nz, y0:y0 + ny, x0:x0 + nx])
     w, h = int(rng.integers(200, 641)), int(rng.integers(200, 481))
-    kw = dict(mode=int(rng.integers(0, 3)), cloud_size_m=float(rng.choice([3000.0, 7000.0, 15000.0])),
+    kw = dict(mode=int(rng.integers(0, 3)), estimator=int(rng.random() < 0.4), cloud_size_m=float(rng.choice([3000.0, 7000.0, 15000.0])),
               light_direction=tuple(float(v) for v in rng.normal(size=3)), max_depth=int(rng.choice([100, 2000])))
     eye = rng.normal(size=3); eye = tuple(float(v) for v in eye / np.linalg.norm(eye) * rng.uniform(1.2, 3.0))
     tr = ds.CloudTracer(tex, width=w, height=h, **kw)

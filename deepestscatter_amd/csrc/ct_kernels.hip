@@ -5,7 +5,8 @@
 //                              wave-scheduled state machine: path regeneration from a job queue, march
 //                              bursts / scatter phases, exact free-space skipping, suspension of the
 //                              surviving paths at the end of a launch and their resumption by the next
-//   render_delta_kernel        the same scheduler around Woodcock tracking over brick majorants (DELTA)
+//   render_delta_kernel        the same scheduler around Woodcock tracking over a grid of majorant cells that
+//                              every block keeps in LDS (DELTA); majorant_cells_kernel builds the grid
 //   render_simple_kernel       the MARCH estimator, one thread per pixel, nested loops (A/B and cross-check)
 //   primary_rays_kernel, primary_advance_kernel, primary_advance_delta_kernel
 //                              per pose: primary ray per pixel and the part of its flight that is the same

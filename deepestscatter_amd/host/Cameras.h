@@ -45,7 +45,7 @@ namespace DeepestScatter
             s.mie_host = context->mie.data();
             s.chopped_mie_host = context->choppedMie.data();
             s.mie_count = (uint32_t)context->mie.size();
-            s.estimator = CT_EST_MARCH;
+            s.estimator = estimator;
             context->destroy();
             Context::check(ct_create(&s, &context->handle), nullptr, "ct_create");
             context->density.clear();
@@ -64,6 +64,7 @@ namespace DeepestScatter
         }
 
         uint32_t subframeId = 0;        // context["subframeId"], set by Camera::render (Camera.cpp:191-192)
+        int estimator = CT_EST_MARCH;   // CT_EST_DELTA: Woodcock tracking instead of the reference's fixed-step march
         inline static const std::string NAME = "PT";
 
     private:

@@ -4,7 +4,7 @@
 // (GuiExecutionLoop.cpp:85-128) becomes a plain while(!scene->isCompleted()) scene->update().
 //
 //   cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light Side|Back|Front]
-//              [--size-m 7000] [--out DIR] [--data DIR] [--unfused] [--display] [--format exr|pfm]
+//              [--size-m 7000] [--out DIR] [--data DIR] [--unfused] [--display] [--estimator march|delta] [--format exr|pfm]
 //   <cloud> = procedural:<N>[:<seed>] | file.f32grid
 #include <chrono>
 #include <cstring>
@@ -46,6 +46,7 @@ namespace
         std::string outDir = ".", dataDir, format = "exr";
         bool fused = true;
         bool display = false;                                                     // --display: tonemap + convergence test after every update, like the GUI
+        int estimator = CT_EST_MARCH;                                             // --estimator delta: Woodcock tracking (not the reference's sampler)
     };
 
     using LazyTask = std::function<std::shared_ptr<Scene>()>;
@@ -67,6 +68,7 @@ namespace
             auto outputPath = std::filesystem::path(opt.outDir) / (stem + "." + toString(lightDirection) + "." + PathTracingRenderer::NAME + "." + opt.format);
             // installFramework + installApp: Sun, VDBCloud, CloudMaterial, Camera in this order (installers.cpp:28-38)
             auto renderer = std::make_shared<PathTracingRenderer>(context);
+            renderer->estimator = opt.estimator;
             auto sun = std::make_shared<Sun>(std::make_shared<DirectionalLight>(scene.light), context);
             auto cloud = std::make_shared<VDBCloud>(std::make_shared<Cloud::Model>(scene.cloud.model), context, resources);
             auto material = std::make_shared<CloudMaterial>(std::make_shared<Cloud::Rendering>(scene.cloud.rendering), context);
@@ -86,7 +88,7 @@ int main(int argc, char* argv[])
     try
     {
         Options opt;
-        if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused] [--display] [--format exr|pfm]\n"; return 2; }
+        if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused] [--display] [--estimator march|delta] [--format exr|pfm]\n"; return 2; }
         opt.cloud = argv[1];
         opt.dataDir = (std::filesystem::path(argv[0]).parent_path() / ".." / "data").string();
         for (int i = 2; i < argc; i++)
@@ -100,6 +102,13 @@ int main(int argc, char* argv[])
             else if (a == "--data") opt.dataDir = next();
             else if (a == "--unfused") opt.fused = false;
             else if (a == "--display") opt.display = true;
+            else if (a == "--estimator")
+            {
+                const std::string e = next();
+                if (e == "march") opt.estimator = CT_EST_MARCH;
+                else if (e == "delta") opt.estimator = CT_EST_DELTA;
+                else throw std::invalid_argument("--estimator march|delta");
+            }
             else if (a == "--format") { opt.format = next(); if (opt.format != "exr" && opt.format != "pfm") throw std::invalid_argument("--format exr|pfm"); }
             else if (a == "--mode")
             {

@@ -350,6 +350,18 @@ def test_cpp_host_cli_matches_python_path(tmp_path):
             raw = path.read_bytes()
             assert raw[:8] == b"\x76\x2f\x31\x01\x02\x00\x00\x00" and b"lineOrder\0lineOrder\0\x01\0\0\0\x01" in raw
         assert np.array_equal(img, want)
+    # --estimator delta: the same host classes around Woodcock tracking
+    tr = ds.CloudTracer(tex, width=40, height=24, light_direction=ds.LIGHT_DIRECTIONS["Back"], estimator=1)
+    tr.render_accumulate(1, 5)
+    want_delta = tr.mean()[..., :3]
+    tr.close()
+    out = tmp_path / "d"
+    out.mkdir()
+    r = subprocess.run([str(cli), "procedural:32", "--size", "40x24", "--spp", "5", "--light", "Back", "--estimator", "delta",
+                        "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(exr.read_exr(out / "procedural_32.Back.PT.exr"), want_delta)
+    assert not np.array_equal(want_delta, want)
     bad = subprocess.run([str(cli), "procedural:32", "--mode", "bogus"], capture_output=True, text=True)
     assert bad.returncode == 1 and "Invalid Render Mode" in bad.stdout      # CloudMaterial.cpp:62 / main.cpp:65-76
 

@@ -351,3 +351,38 @@ def test_exr_writer_reader_round_trip(tmp_path):
         assert np.array_equal(exr.read_exr(p), img)
     # size = header + offset table + height * (8 + 3 * width * 4)
     assert len(raw) - raw.index(b"screenWindowWidth") < 40 + 8 * 9 + 9 * (8 + 3 * 13 * 4)
+
+
+def test_delta_lower_bound_codes_only_skip_lookups():
+    """DELTA's per-cell lower bound (2-bit code q, texel value (q*M) >> 2 <= the cell's smallest texel): a collision
+    below it is accepted without a lookup.  That must never change a decision -- with the codes zeroed (no bound) the
+    image is the same bit for bit and only the lookup counter is larger -- and the bound must really hold for
+    every cell."""
+    rng = np.random.default_rng(5)
+    nz, ny, nx = 20, 24, 28
+    tex = rng.integers(90, 256, (nz, ny, nx)).astype(np.uint8)          # dense everywhere: large minima
+    tex[:, :, :6] = rng.integers(0, 40, (nz, ny, 6)).astype(np.uint8)     # and a thin part with small ones
+    o = O.Oracle(tex, 24, 16, mode=0, estimator=1, cloud_size_m=700.0)
+    M, q = o.majorant.astype(np.int64), o.majorant_codes.astype(np.int64)
+    s = o.scene
+    bias, c = s.maj_bias, 1 << s.maj_shift
+    gz, gy, gx = M.shape
+    for cz in range(gz):
+        for cy in range(gy):
+            for cx in range(gx):
+                zs = np.clip(np.arange(c * cz - bias - 1, c * cz - bias + c + 2), 0, nz - 1)
+                ys = np.clip(np.arange(c * cy - bias - 1, c * cy - bias + c + 2), 0, ny - 1)
+                xs = np.clip(np.arange(c * cx - bias - 1, c * cx - bias + c + 2), 0, nx - 1)
+                blk = tex[np.ix_(zs, ys, xs)]
+                assert M[cz, cy, cx] == blk.max()
+                assert 0 <= q[cz, cy, cx] <= 3 and (q[cz, cy, cx] * M[cz, cy, cx]) >> 2 <= blk.min()
+    assert (q > 0).any()
+    mean, m2 = o.render(3)
+    with_bound = o.counters.as_dict()
+    o2 = O.Oracle(tex, 24, 16, mode=0, estimator=1, cloud_size_m=700.0)
+    o2.majorant_codes[...] = 0
+    mean2, m22 = o2.render(3)
+    without = o2.counters.as_dict()
+    assert np.array_equal(mean, mean2) and np.array_equal(m2, m22)
+    assert with_bound["scatter_events"] == without["scatter_events"]
+    assert with_bound["density_lookups"] < without["density_lookups"]

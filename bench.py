@@ -13,8 +13,8 @@ radiance buffer to rank 0.  Two steps are one 1024-spp image of BASELINE.json's 
 of a 1024^2 frame are what the 8 GiB per-batch sample scratch holds).  (The reference updates its display
 every 10 subframes and saves every 40, Camera.cpp:189,211; a launch ends with a tail of waves that
 finish its long paths unless it may hand them to the next launch, which is what the enqueued steps of this
-benchmark do: 2280 Msamples/s at 64 spp per launch, 2540 at 128, 2730 at 256, 2855 at 512; waiting for every
-step: 1690, 2110, 2480, 2590.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
+benchmark do; measured when the kernel ran 2855 Msamples/s at 512 spp per launch: 2280 at 64, 2540 at 128, 2730
+at 256; waiting for every step: 1690, 2110, 2480, 2590.)  Inputs are synthetic (procedural cloud of SURVEY.md section 8d, generated on the host
 before the timed region and resident in HBM).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations

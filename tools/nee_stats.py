@@ -1,5 +1,8 @@
+"""Hit rate of the march kernel's per-lane NEE footprint cache on the benchmark scene (needs CT_STATS=1)."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+assert os.environ.get("CT_STATS"), "run with CT_STATS=1"
 import torch
 import deepestscatter_amd as ds
 t = ds.CloudTracer(ds.make_procedural_cloud(512), width=1024, height=1024)

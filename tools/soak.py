@@ -26,10 +26,23 @@ for case in range(cases):
         (tr.render_accumulate_async if a else tr.render_accumulate)(first, int(n))
         pattern.append((int(n), a)); first += int(n)
     mean, m2 = orc.render(first - 1)
-    ok = np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2) and tr.counters() == orc.counters.as_dict()
+    got_mean, got_m2, got_counters = tr.mean(), tr.m2(), tr.counters()
+    ok = np.array_equal(got_mean, mean) and np.array_equal(got_m2, m2) and got_counters == orc.counters.as_dict()
     if not ok:
         bad += 1
         print(f"MISMATCH seed {seed} case {case}: dims {tex.shape[::-1]} {w}x{h} {kw} eye {eye} batches {pattern}", flush=True)
+        # what differs, and whether a second render of the same handle agrees with the first (a schedule-dependent result)
+        dm, dv = got_mean != mean, got_m2 != m2
+        print(f"   mean differs at {int(dm.any(axis=-1).sum())} pixels (max abs {float(np.abs(got_mean - mean).max()):.3e}), "
+              f"m2 at {int(dv.any(axis=-1).sum())}; first pixels {np.argwhere(dm.any(axis=-1))[:4].tolist()}; counters hip {got_counters} "
+              f"oracle {orc.counters.as_dict()}", flush=True)
+        tr.reset()
+        first2 = 1
+        for n, a in pattern:
+            (tr.render_accumulate_async if a else tr.render_accumulate)(first2, n)
+            first2 += n
+        print(f"   same handle, same batches again: mean equal to oracle {np.array_equal(tr.mean(), mean)}, to first run "
+              f"{np.array_equal(tr.mean(), got_mean)}", flush=True)
     tr.close()
     if case % 50 == 49:
         print(f"{case + 1} cases, {bad} mismatches", flush=True)

@@ -7,10 +7,12 @@ reduce of the accumulated radiance buffer).
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one progressive batch of --spp-per-step (default 512 x n_gpus) subframes of the whole
-frame: estimator kernel + Welford accumulate kernel, plus (N>1) the reduce of the W*H float4
-radiance buffer to rank 0.  Two steps are one 1024-spp image of BASELINE.json's configuration (512 subframes
-of a 1024^2 frame are what the 8 GiB per-batch sample scratch holds).  (The reference updates its display
+A "step" = the 1024-spp job of BASELINE.json configs[2]/[3]: --spp-per-step (default 1024) subframes of the whole
+frame, whatever N is ("scaling": "strong" -- rank r renders its 1/N of the 8x8-pixel tiles for all 1024 subframes):
+estimator kernel(s) + Welford accumulate kernel(s), plus (N>1) ONE RCCL SUM-reduce of the merged [mean | M2]
+buffer (2 x W*H float4) to rank 0.  At N=1 a step is two launches of 512 subframes (what the 8 GiB per-batch sample
+scratch holds at 1024^2); at N=8 one launch of 1024 subframes over an eighth of the pixels.  --weak gives every
+GPU the same work per step instead (512 x N subframes per step: round 1's definition).  (The reference updates its display
 every 10 subframes and saves every 40, Camera.cpp:189,211; a launch ends with a tail of waves that
 finish its long paths unless it may hand them to the next launch, which is what the enqueued steps of this
 benchmark do; measured when the kernel ran 2855 Msamples/s at 512 spp per launch: 2280 at 64, 2540 at 128, 2730
@@ -32,6 +34,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MEASURED_COPY_GBS = 6290.0          # the same guide: float4 copy, 79 % of spec
+MEASURED_RANDOM_LINE_GBS = 7100.0   # tools/probes/gather_probe.hip: 55 G random 128-B lines per second from beyond L2
 
 
 def parse_args():
@@ -43,8 +47,12 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp-per-step", type=int, default=0,
-                    help="subframes per progressive batch (one estimator launch + one accumulate launch); "
-                         "default 512 x n_gpus, i.e. a constant number of samples per GPU per launch")
+                    help="subframes per step; default 1024 (the fixed job of BASELINE.json configs[2]/[3], strong scaling), "
+                         "512 x n_gpus with --weak")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: 512 x n_gpus subframes per step (constant work per GPU)")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 --pmc child runs of this command (N=1 only; "
+                         "two short child runs before this process touches the GPU); fall back to profiles/pmc_latest.json")
     ap.add_argument("--mode", type=int, default=0, help="0 totalRadiance (Mie multi-scatter + NEE)")
     ap.add_argument("--estimator", type=int, default=0, choices=(0, 1),
                     help="0 MARCH = the reference's free-flight sampler (the parity path, default); "
@@ -92,6 +100,76 @@ def cpu_baseline(tex, ins, width, height, mode, target_s):
     }
 
 
+def pmc_traffic(args, S):
+    """roofline.traffic, measured live: two short child runs of this same command under `rocprofv3 --pmc` (FETCH_SIZE
+    and WRITE_SIZE need separate passes: MI355X_MICROARCH.md, HBM section), started BEFORE this process touches the
+    GPU.  Returns bytes across the L2's memory side for one full launch of `launch_spp` subframes and for one
+    resume-only launch, FETCH_SIZE doubled (the guide's gfx950 correction, re-calibrated on this kernel's access
+    pattern by tools/fetch_probe.py: 64 B reported per 128-B line) -- or None when the profiler cannot run here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(exe).exists() or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("CT_BENCH_CHILD"):
+        return None
+    # (one step of the child is S subframes; the library cuts it into launches of at most 512 at 1024^2)
+    child = [sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-delta-leg",
+             "--no-pmc-traffic", "--volume", str(args.volume), "--width", str(args.width), "--height", str(args.height),
+             "--spp-per-step", str(S), "--mode", str(args.mode), "--estimator", str(args.estimator)]
+    env = dict(os.environ, CT_BENCH_CHILD="1", TMPDIR="/tmp")
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="ct_pmc_", dir="/tmp")
+    try:
+        for counters in (["FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]):
+            d = os.path.join(tmp, counters[0])
+            r = subprocess.run([exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=420)
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {' '.join(counters)} failed ({r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
+            per = {}
+            for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
+                if "render_persistent_kernel" in row["Kernel_Name"] or "render_delta_kernel" in row["Kernel_Name"]:
+                    per.setdefault(row["Counter_Name"], []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"]),
+                                                                    int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+            for name, rows in per.items():
+                rows.sort()
+                out[name] = rows
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"roofline"' in l]
+            if not lines:
+                return {"error": "the child printed no bench line: " + (r.stderr or r.stdout)[-300:]}
+            child_line = json.loads(lines[-1])
+        # Launch order of the child: cost-measuring launch + rest of the warm-up step, resume-only launch of the fence,
+        # the n_t launches of the timed step, resume-only launch of the final fence.  n_t from the child's own line.
+        n_t = max(int(child_line["roofline"]["launches"]), 1)
+        fetch, write = out["FETCH_SIZE"], out["WRITE_SIZE"]
+        if len(fetch) < n_t + 1 or len(write) != len(fetch):
+            return {"error": f"unexpected dispatch count {len(fetch)}/{len(write)} for {n_t} timed launches"}
+        full = lambda rows: rows[-1 - n_t:-1]
+        res = {
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum: two child runs of this command "
+                      "(1 warm-up + 1 timed step) before the timed process started; FETCH_SIZE x 2 (gfx950: a 128-B request is "
+                      "tallied as 64 B -- MI355X_MICROARCH.md HBM section, re-calibrated by tools/fetch_probe.py) + WRITE_SIZE, "
+                      "KiB -> bytes; Infinity-Cache hits are inside this figure (it is traffic across the L2's memory side)",
+            "full_launch_bytes": (2.0 * sum(r[1] for r in full(fetch)) + sum(r[1] for r in full(write))) * 1024.0 / n_t,
+            "resume_launch_bytes": (2.0 * fetch[-1][1] + write[-1][1]) * 1024.0,
+            "full_launch_ms_under_pmc": sum(r[2] for r in full(fetch)) / n_t / 1e6,
+            "full_launches_measured": n_t,
+            "dispatch_ms_under_pmc": [round(r[2] / 1e6, 2) for r in fetch],
+        }
+        miss, hit = out.get("TCC_MISS_sum"), out.get("TCC_HIT_sum")
+        if miss and hit and len(miss) == len(fetch):
+            res["tcc_miss_per_full_launch"] = sum(r[1] for r in full(miss)) / n_t
+            res["l2_hit_rate"] = sum(r[1] for r in full(hit)) / max(sum(r[1] for r in full(hit)) + sum(r[1] for r in full(miss)), 1.0)
+        return res
+    except Exception as e:  # the figure is optional; the bench line is not
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def delta_leg(ds, tex, W, H, mode, S, steps):
     """The same workload with the DELTA estimator (Woodcock tracking, BASELINE.json north_star's algorithm; unbiased,
     not the reference's sampler, so it cannot be the parity path -- DESIGN.md 4.2), reported beside the headline:
@@ -109,11 +187,12 @@ def delta_leg(ds, tex, W, H, mode, S, steps):
     t.close()
     lookups = (k1["density_lookups"] - k0["density_lookups"]) + (k1["inscatter_lookups"] - k0["inscatter_lookups"])
     paths = k1["paths"] - k0["paths"]
-    alg = 8 * lookups + 16 * paths
+    alg = 8 * lookups + 16 * paths   # this kernel issues one fetch per counted lookup: issued bytes == algorithmic bytes
     return {"estimator": "DELTA (Woodcock tracking over LDS-resident majorant cells)", "value": W * H * S * steps / dt / 1e6,
             "unit": "Msamples/s", "ms_per_step": dt / steps * 1e3, "kernel": "render_delta_kernel",
             "avg_launch_ms": (r1 - r0) / max(l1 - l0, 1), "lookups_per_sample": lookups / max(paths, 1),
-            "roofline_frac": alg / ((r1 - r0) * 1e-3) / 1e9 / HBM_PEAK_GBS if r1 > r0 else 0.0}
+            "issued_frac": alg / ((r1 - r0) * 1e-3) / 1e9 / HBM_PEAK_GBS if r1 > r0 else 0.0,
+            "note": "issue-bound, not memory-bound (DESIGN.md 4.2); fabric traffic per launch: profiles/"}
 
 
 def main():
@@ -125,6 +204,13 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+
+    W, H = args.width, args.height
+    S = args.spp_per_step if args.spp_per_step > 0 else (512 * world if args.weak else 1024)
+    # roofline.traffic from the hardware counters, before anything here touches the GPU (child processes)
+    pmc = None
+    if world == 1 and not args.no_pmc_traffic and not args.simple_kernel:
+        pmc = pmc_traffic(args, S)
 
     import torch
     import torch.distributed as dist
@@ -144,8 +230,6 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    W, H = args.width, args.height
-    S = args.spp_per_step if args.spp_per_step > 0 else 512 * world
     t_setup = time.perf_counter()
     tex = ds.make_procedural_cloud(args.volume)
     flags = _lib.CT_FLAG_SIMPLE_KERNEL if args.simple_kernel else 0
@@ -181,7 +265,7 @@ def main():
     for _ in range(args.warmup):
         step(nxt)
         nxt += S
-    k0 = tr.counters()
+    k0, f0 = tr.counters(), tr.fetch_counters()
     r0, a0, l0 = tr.kernel_time()
     fence()
     t0 = time.perf_counter()
@@ -197,7 +281,7 @@ def main():
     gc.enable()
     if os.environ.get("CT_BENCH_VERBOSE") and rank == 0:
         print("step end marks (ms) [and cumulative kernel ms]:", ["%.2f" % (m * 1e3 if m < 50 else m) for m in step_marks], "total %.2f" % (elapsed * 1e3), file=sys.stderr)
-    k1 = tr.counters()
+    k1, f1 = tr.counters(), tr.fetch_counters()
     r1, a1, l1 = tr.kernel_time()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -208,39 +292,71 @@ def main():
     total_samples = W * H * S * args.steps
     value = total_samples / elapsed / 1e6
 
-    # ---- roofline of the dominant kernel (the estimator), this rank's launches in the timed region
+    # ---- roofline of the dominant kernel (the estimator), this rank's launches in the timed region.
+    # Three byte counts per launch, all over the same HIP-event launch durations (the handle's stream):
+    #   algorithmic  8 B per trilinear lookup THE ALGORITHM makes (density or shadow volume; = the oracle's counters)
+    #                + the 16 B float4 result each sample writes.  The MARCH kernel does not fetch most of them (exact
+    #                free-space replay, the pre-walked primary prefix, reused shadow-volume footprints), so this figure
+    #                may exceed the peak: it says how much work was avoided, not how busy the memory system is.
+    #   issued       8 B per footprint the kernel actually loaded (ct_fetch_counters) + 16 B per sample written.
+    #   traffic      bytes across the L2's memory side from the PMC counters (every issued footprint that misses L2
+    #                moves a whole 128-B line for its 16 useful bytes).
+    # `achieved` = max(issued, traffic) / time -- what the memory system really moved -- and `frac` = achieved / peak.
     dk = {k: k1[k] - k0[k] for k in k1}
+    df = {k: f1[k] - f0[k] for k in f1}
     launches = max(l1 - l0, 1)
     render_ms = r1 - r0
+    sec = render_ms * 1e-3
     lookups = dk["density_lookups"] + dk["inscatter_lookups"]
-    # algorithmic bytes: 8 B per trilinear lookup (density or shadow volume) + the 16 B float4 result
-    # each sample writes (accumulation's 64 B/pixel/batch belongs to the second, tiny kernel)
+    fetches = df["density_fetches"] + df["inscatter_fetches"]
     alg_bytes = 8 * lookups + 16 * dk["paths"]
-    achieved = alg_bytes / (render_ms * 1e-3) / 1e9 if render_ms > 0 else 0.0
-    # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of this same command (PMC
-    # collection cannot run inside the timed process); profiles/pmc_latest.json holds the figure, its
-    # calibration and the launch configuration it is valid for.
-    traffic = None
-    pmc = ROOT / "profiles" / "pmc_latest.json"
-    if pmc.exists() and world == 1 and not args.simple_kernel and args.estimator == 0:
-        try:
-            rec = json.loads(pmc.read_text())
-            lc = rec.get("launch_config", {})
-            if (lc.get("spp_per_step"), lc.get("volume"), lc.get("width"), lc.get("height")) == (S, args.volume, W, H):
-                traffic = rec.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    issued_bytes = 8 * fetches + 16 * dk["paths"]
+    # (`launches` counts the full launches; the resume-only launch that ends a run of enqueued steps is booked into
+    # render_ms -- it belongs to the estimator's time -- but not counted, so "per launch" means per full launch here)
+    resume_launches = 0 if args.sync_steps else 1
+    traffic, traffic_source, pmc_extra = None, None, {}
+    if pmc and "error" not in pmc:
+        traffic = (launches * pmc["full_launch_bytes"] + resume_launches * pmc["resume_launch_bytes"]) / launches
+        traffic_source = pmc["source"]
+        pmc_extra = {k: pmc[k] for k in ("full_launch_bytes", "resume_launch_bytes", "full_launch_ms_under_pmc", "dispatch_ms_under_pmc",
+                                         "tcc_miss_per_full_launch", "l2_hit_rate") if k in pmc}
+    else:
+        # no profiler here: the committed figure of the same launch configuration, if there is one
+        f = ROOT / "profiles" / "pmc_latest.json"
+        if f.exists() and world == 1 and not args.simple_kernel and args.estimator == 0:
+            try:
+                rec = json.loads(f.read_text())
+                lc = rec.get("launch_config", {})
+                if (lc.get("volume"), lc.get("width"), lc.get("height")) == (args.volume, W, H) and S % lc.get("spp_per_launch", 512) == 0:
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_latest.json (committed rocprofv3 --pmc run of this command; not measured in this run" + \
+                                     (": " + pmc["error"] if pmc else "") + ")"
+            except Exception:
+                traffic = None
+    achieved_bytes = max(issued_bytes / launches, traffic or 0.0)
+    achieved = achieved_bytes * launches / sec / 1e9 if sec > 0 else 0.0
     roofline = {
         "bound": "hbm",
         "kernel": "render_simple_kernel" if args.simple_kernel else ("render_delta_kernel" if args.estimator else "render_persistent_kernel"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic,
+        "achieved_is": "max(issued bytes, PMC traffic) per launch / average launch duration",
+        "traffic": traffic, "traffic_source": traffic_source,
+        "issued_bytes_per_launch": issued_bytes / launches,
+        "issued_GBps": issued_bytes / sec / 1e9 if sec > 0 else 0.0,
         "algorithmic_bytes_per_launch": alg_bytes / launches,
+        "algorithmic_GBps": alg_bytes / sec / 1e9 if sec > 0 else 0.0,
+        "algorithmic_over_peak": alg_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
+        # measured ceilings ("use the measured ceiling as denominator too")
+        "peak_measured": {"float4_copy_GBps": MEASURED_COPY_GBS, "random_128B_line_GBps": MEASURED_RANDOM_LINE_GBS,
+                          "source": "MI355X_MICROARCH.md (copy); profiles/gather_probe.txt (one random 128-B line per lane, working set >= 256 MiB)"},
+        "frac_of_measured_copy": achieved / MEASURED_COPY_GBS,
+        "frac_of_random_line_probe": achieved / MEASURED_RANDOM_LINE_GBS,
         "avg_launch_ms": render_ms / launches, "launches": launches,
-        "lookups_per_s": lookups / (render_ms * 1e-3) if render_ms > 0 else 0.0,
         "lookups_per_sample": lookups / max(dk["paths"], 1),
+        "fetches_per_sample": fetches / max(dk["paths"], 1),
         "accumulate_ms_per_launch": (a1 - a0) / launches,
-        "counters_per_launch": {k: v / launches for k, v in dk.items()},
+        "counters_per_launch": {k: v / launches for k, v in {**dk, **df}.items()},
+        **pmc_extra,
     }
 
     if os.environ.get("CT_STATS"):
@@ -249,17 +365,17 @@ def main():
         "metric": "Msamples/s (rays x spp) at 512^3 vol, 1024^2 frame; HBM GB/s vs roofline",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        # every GPU renders its 1/N of the tiles for 512 x N subframes per step: constant work per GPU per step
-        "scaling": "weak",
+        # strong: the fixed 1024-spp job, rank r renders its 1/N of the tiles; --weak: 512 x N subframes per step
+        "scaling": "weak" if args.weak else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{args.volume}^3 procedural density, {W}x{H}, progressive, {S} spp per step "
-                        f"(BASELINE.json configs[{2 if world == 1 else 3}]: a 1024 spp job is {1024 / max(S, 1):g} such steps), "
+                        f"(BASELINE.json configs[{2 if world == 1 else 3}]: a 1024 spp job is {1024 / max(S, 1):g} such step(s)), "
                         f"mode {('totalRadiance','multipleScatterSunRadiance','singleScatterSunRadiance')[args.mode]} "
                         "(Mie multi-scatter + NEE), estimator "
                         f"{('MARCH (reference-faithful)', 'DELTA (Woodcock, LDS-resident majorant cells)')[args.estimator]}, max_depth 2000",
             "volume": args.volume, "width": W, "height": H, "spp_per_step": S,
-            "parallelism": f"pixel-tile shard x{world}" + (" + RCCL reduce of the radiance buffer" if world > 1 else ""),
+            "parallelism": f"pixel-tile shard x{world}" + (" + RCCL reduce of the [mean | M2] buffer per step" if world > 1 else ""),
             "pipelined_steps": not args.sync_steps,
         },
         "roofline": roofline,

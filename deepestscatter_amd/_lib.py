@@ -19,9 +19,9 @@ CT_FLAG_NONE, CT_FLAG_SIMPLE_KERNEL, CT_FLAG_LIGHT_NORMALIZED = 0, 1, 2
 # every symbol include/cloudtrace.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ct_create", "ct_destroy", "ct_last_error", "ct_set_stream", "ct_set_camera", "ct_render_subframe",
-    "ct_accumulate", "ct_render_accumulate", "ct_render_accumulate_async", "ct_synchronize", "ct_copy_to_device_async", "ct_point_radiance_launch", "ct_generate_scatter_samples", "ct_collect_descriptors", "ct_reset", "ct_tonemap", "ct_is_converged", "ct_download",
+    "ct_accumulate", "ct_render_accumulate", "ct_render_accumulate_async", "ct_synchronize", "ct_copy_to_device_async", "ct_point_radiance_launch", "ct_generate_scatter_samples", "ct_collect_descriptors", "ct_reset", "ct_tonemap", "ct_is_converged", "ct_tonemap_buffer", "ct_is_converged_buffers", "ct_download",
     "ct_buffer_bytes", "ct_copy_to_device", "ct_device_ptr", "ct_subframes", "ct_set_subframes", "ct_counters", "ct_kernel_time",
-    "ct_debug_cdf_inversion", "ct_debug_fetch_probe", "ct_debug_stats", "ct_debug_suspended", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_generate_mipmaps",
+    "ct_debug_cdf_inversion", "ct_debug_fetch_probe", "ct_debug_stats", "ct_debug_suspended", "ct_debug_invariants", "ct_fetch_counters", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_generate_mipmaps",
     "ct_tile_owner", "ct_make_procedural_cloud",
 ]
 
@@ -66,6 +66,13 @@ class CtCounters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class CtFetchCounters(C.Structure):
+    _fields_ = [("density_fetches", C.c_uint64), ("inscatter_fetches", C.c_uint64)]
+
+    def as_dict(self) -> dict:
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 class CloudTraceError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"libcloudtrace error {code}: {message}")
@@ -104,6 +111,8 @@ def load():
         "ct_reset": (i32, [vp]),
         "ct_tonemap": (i32, [vp, f32, vp, C.POINTER(f32)]),
         "ct_is_converged": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_uint64)]),
+        "ct_tonemap_buffer": (i32, [vp, vp, f32, vp, C.POINTER(f32)]),
+        "ct_is_converged_buffers": (i32, [vp, vp, vp, u32, C.POINTER(i32), C.POINTER(C.c_uint64)]),
         "ct_download": (i32, [vp, i32, vp, C.c_size_t]),
         "ct_buffer_bytes": (i32, [vp, i32, C.POINTER(C.c_size_t)]),
         "ct_copy_to_device": (i32, [vp, i32, vp, C.c_size_t]),
@@ -116,6 +125,8 @@ def load():
         "ct_kernel_time": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "ct_debug_cdf_inversion": (i32, [vp, u32, u32, vp]),
         "ct_debug_stats": (i32, [vp, vp]),
+        "ct_debug_invariants": (i32, [vp, vp]),
+        "ct_fetch_counters": (i32, [vp, C.POINTER(CtFetchCounters)]),
         "ct_debug_fetch_probe": (i32, [i32, u32, u32, C.POINTER(C.c_uint64)]),
         "ct_calculate_camera_variables": (i32, [vp, vp, vp, f32, f32, vp, vp, vp]),
         "ct_quantize_volume": (i32, [vp, vp, vp]),

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (CT_BUF_DENSITY, CT_BUF_FRAME, CT_BUF_INSCATTER, CT_BUF_M2, CT_BUF_MEAN, CT_BUF_SCREEN,
-                   CtCounters, CtScene, check)
+                   CtCounters, CtFetchCounters, CtScene, check)
 
 MIE_FILE = Path(__file__).resolve().parent / "data" / "mie_raw.f32"
 
@@ -248,6 +248,19 @@ class CloudTracer:
         check(self.L.ct_is_converged(self.h, C.byref(ok), C.byref(bad)), self.h)
         return bool(ok.value), int(bad.value)
 
+    def tonemap_buffer(self, mean_dev_ptr: int, exposure: float = 0.4):
+        """ct_tonemap_buffer: the tonemap of a caller-owned W*H float4 device buffer (a merged multi-GPU frame)."""
+        screen = np.empty((self.height, self.width, 4), np.uint8)
+        avg = C.c_float(0)
+        check(self.L.ct_tonemap_buffer(self.h, C.c_void_p(mean_dev_ptr), exposure, _p(screen), C.byref(avg)), self.h)
+        return screen, float(avg.value)
+
+    def is_converged_buffers(self, mean_dev_ptr: int, m2_dev_ptr: int, subframes: int):
+        ok, bad = C.c_int32(0), C.c_uint64(0)
+        check(self.L.ct_is_converged_buffers(self.h, C.c_void_p(mean_dev_ptr), C.c_void_p(m2_dev_ptr), subframes,
+                                             C.byref(ok), C.byref(bad)), self.h)
+        return bool(ok.value), int(bad.value)
+
     # -- data ---------------------------------------------------------------------------------------
     def download(self, which: int) -> np.ndarray:
         n = C.c_size_t(0)
@@ -301,6 +314,19 @@ class CloudTracer:
         c = CtCounters()
         check(self.L.ct_counters(self.h, C.byref(c)), self.h)
         return c.as_dict()
+
+    def fetch_counters(self) -> dict:
+        """What the kernels issued for the lookups `counters()` reports (ct_fetch_counters)."""
+        c = CtFetchCounters()
+        check(self.L.ct_fetch_counters(self.h, C.byref(c)), self.h)
+        return c.as_dict()
+
+    def debug_invariants(self) -> dict:
+        """Path conservation / sample integrity tallies (ct_debug_invariants)."""
+        out = np.zeros(8, np.uint64)
+        check(self.L.ct_debug_invariants(self.h, _p(out)), self.h)
+        names = ["armed", "checks", "violations", "samples_without_alpha_1", "dealt", "resumed", "written", "suspended"]
+        return {n: int(v) for n, v in zip(names, out)}
 
     def kernel_time(self):
         """-> (estimator kernel ms, accumulate kernel ms, estimator launches) since create/reset."""

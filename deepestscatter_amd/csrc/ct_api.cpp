@@ -95,8 +95,15 @@ struct CtHandle_ {
     unsigned long long *d_counters = nullptr; // kCounterCount + 1 (unconverged) + kStatCount
     float *d_colsum = nullptr, *d_avg = nullptr;
 
+    // CT_DEBUG_INVARIANTS=1: the diagnostics build of the estimator counts samples dealt / paths resumed / results
+    // written / paths suspended, the scratch is filled with NaNs before every launch, and every point at which
+    // nothing is in flight checks: dealt + resumed == written + suspended, resumed == suspended, dealt == what the
+    // host handed out, no sample without alpha 1 reached an accumulate kernel.  A violation fails the call.
+    bool debug_invariants = false;
+    uint64_t iv_expected_dealt = 0, iv_checks = 0, iv_violations = 0;
+
     size_t volume_bytes = 0;
-    LaunchShape shape{ 1024, 256 };
+    LaunchShape shape{ 1024, 256, false };
     uint32_t subframes = 0;
     double render_ms = 0, accum_ms = 0;
     uint64_t launches = 0;
@@ -130,6 +137,7 @@ static int fail(CtHandle h, int code, const char *fmt, ...)
     } while (0)
 
 static int flush(CtHandle h);
+static int check_invariants(CtHandle h);
 
 #define NEED_NOFLUSH(h)                                \
     do {                                               \
@@ -291,6 +299,10 @@ static int create_impl(const CtScene *s, CtHandle h)
         HIPCHK(h, hipEventCreate(&e));
     }
     h->shape = persistent_shape(s->device, s->estimator == CT_EST_DELTA);
+    if (const char *e = getenv("CT_DEBUG_INVARIANTS")) {
+        h->debug_invariants = atoi(e) != 0;
+    }
+    h->shape.stats = getenv("CT_STATS") != nullptr || h->debug_invariants;
 
     // ---- uniforms: VDBCloud::setupVolumeVariables (VDBCloud.cpp:98-111), Sun::init (Sun.cpp:13-18)
     DevScene &d = h->dev;
@@ -556,7 +568,7 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, dmalloc(&h->d_m2, pixels));
     HIPCHK(h, dmalloc(&h->d_screen, pixels));
     HIPCHK(h, dmalloc(&h->d_colsum, s->width));
-    HIPCHK(h, dmalloc(&h->d_avg, 1));
+    HIPCHK(h, dmalloc(&h->d_avg, 2)); // average luminance + the fused tonemap kernel's grid barrier
     HIPCHK(h, dmalloc(&h->d_queue, kQueueWords));
     HIPCHK(h, dmalloc(&h->d_cont_count, 3));
     HIPCHK(h, hipMemsetAsync(h->d_cont_count, 0, 3 * sizeof(uint32_t), h->stream));
@@ -625,8 +637,9 @@ extern "C" int ct_create(const CtScene *s, CtHandle *out)
                     s->height);
     }
     if (!(s->sample_step > 0.f) || !(s->sample_step <= 0.03125f) || !(s->cloud_size_m > 0.f) ||
-        !(s->mean_free_path_m > 0.f) || s->max_depth < 2) {
-        return fail(nullptr, CT_E_INVAL, "sample_step/cloud_size_m/mean_free_path_m/max_depth out of range");
+        !(s->mean_free_path_m > 0.f) || s->max_depth < 2 || s->max_depth > 65535) {
+        // (a suspended path carries its depth in 16 bits: BatchArgs::cont_out)
+        return fail(nullptr, CT_E_INVAL, "sample_step/cloud_size_m/mean_free_path_m/max_depth out of range (max_depth 2..65535)");
     }
     if (!(s->cloud_size_m / s->mean_free_path_m * s->sample_step < 80.f)) {
         return fail(nullptr, CT_E_INVAL, "optical depth per step %g too large (must be < 80)",
@@ -999,11 +1012,11 @@ static int enqueue_accumulate(CtHandle h, CtHandle_::Slot &sl, const float4 *fra
     HIPCHK(h, hipEventRecord(sl.ev_acc0, h->stream));
     if (simple || dense) {
         HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width, h->scene.height,
-                                          h->scene.shard_index, h->scene.shard_count, h->stream));
+                                          h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
     } else {
         HIPCHK(h, launch_accumulate_list(frames, h->n_groups * 64u, h->d_pixels, h->n_groups * 64u, h->d_primary,
                                          h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width, h->scene.height,
-                                         h->scene.shard_index, h->scene.shard_count, h->stream));
+                                         h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
     }
     HIPCHK(h, hipEventRecord(sl.ev_acc1, h->stream));
     sl.accumulated = true;
@@ -1055,6 +1068,12 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         HIPCHK(h, hipMemsetAsync(h->d_cont_count + slot, 0, sizeof(uint32_t), h->stream));
     }
     HIPCHK(h, hipMemsetAsync(sl.queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
+    if (h->debug_invariants && !simple && !dense && h->n_groups != 0) {
+        // NaNs (with a NaN alpha) wherever this batch is going to write: a sample that is never written cannot
+        // pass for the one an earlier batch left there
+        HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)slot_frames(h, slot), 0x7fc0deadu, (size_t)S * h->n_groups * 64u * 4u,
+                                    h->stream));
+    }
     HIPCHK(h, hipEventRecord(sl.ev_start, h->stream));
     if (simple) {
         for (uint32_t s = 0; s < S; s++) {
@@ -1074,6 +1093,7 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         }
         h->host_paths += h->own_pixels * S;
         h->host_hits += h->hit_pixels * S;
+        h->iv_expected_dealt += h->hit_pixels * S;
     }
     HIPCHK(h, hipEventRecord(sl.ev_done, h->stream));
     sl.first = first;
@@ -1098,6 +1118,29 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
                 return rc;
             }
         }
+    }
+    return CT_OK;
+}
+
+// Nothing is in flight: the conservation identities of CtHandle_::debug_invariants must hold.
+static int check_invariants(CtHandle h)
+{
+    unsigned long long iv[4] = { 0, 0, 0, 0 }, bad = 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(iv, h->d_counters + kCounterCount + 1 + 64, sizeof iv, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&bad, h->d_counters + 8, sizeof bad, hipMemcpyDeviceToHost));
+    h->iv_checks += 1;
+    const unsigned long long dealt = iv[0], resumed = iv[1], written = iv[2], suspended = iv[3];
+    const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
+    const bool ok = simple || (dealt + resumed == written + suspended && resumed == suspended && dealt == h->iv_expected_dealt &&
+                               bad == 0);
+    if (!ok) {
+        h->iv_violations += 1;
+        fprintf(stderr, "[cloudtrace] INVARIANT VIOLATED: dealt %llu (host expects %llu) resumed %llu written %llu suspended %llu, "
+                        "samples without alpha 1 seen by accumulate: %llu\n",
+                dealt, (unsigned long long)h->iv_expected_dealt, resumed, written, suspended, bad);
+        return fail(h, CT_E_STATE, "invariant violated: dealt %llu (expected %llu) resumed %llu written %llu suspended %llu bad samples %llu",
+                    dealt, (unsigned long long)h->iv_expected_dealt, resumed, written, suspended, bad);
     }
     return CT_OK;
 }
@@ -1155,7 +1198,7 @@ static int flush(CtHandle h)
             return rc;
         }
     }
-    return CT_OK;
+    return h->debug_invariants ? check_invariants(h) : CT_OK;
 }
 
 // Job list etc. for batches of S subframes; everything in flight is waited for when it has to change.
@@ -1232,8 +1275,9 @@ extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *fram
     }
     const float4 *src = frame_rgba_dev ? (const float4 *)frame_rgba_dev : h->d_frame;
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    // (no alpha check here: the caller may accumulate frames of its own)
     HIPCHK(h, launch_accumulate_batch(src, h->d_mean, h->d_m2, subframe_id, 1, h->scene.width, h->scene.height,
-                                      h->scene.shard_index, h->scene.shard_count, h->stream));
+                                      h->scene.shard_index, h->scene.shard_count, nullptr, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev[2]));
     float ms = 0;
@@ -1276,9 +1320,12 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
     uint32_t done = 0;
     // job lists are built for the size of the call's batches, not for the remainder that follows the short
     // cost-measuring launch (the next call of the same size would rebuild them)
-    h->jobs_hint = (uint32_t)std::min<uint64_t>(cap, count);
+    h->jobs_hint = (uint32_t)((count + (count + cap - 1) / cap - 1) / ((count + cap - 1) / cap));
     while (done < count) {
-        uint32_t S = (uint32_t)std::min<uint64_t>(cap, count - done);
+        // what is left, cut into the fewest launches the scratch allows, all of the same size (1024 subframes at
+        // 1024^2, where the scratch holds 624: two launches of 512, not 624 + 400)
+        const uint64_t left = count - done, parts = (left + cap - 1) / cap;
+        uint32_t S = (uint32_t)((left + parts - 1) / parts);
         int rc;
         if (!simple && !h->order_tuned) {
             // the first launch of a pose measures the job costs (two atomics per path, jobs in image
@@ -1439,6 +1486,7 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         h->render_ms += ms;
         h->launches += 1;
         h->host_paths += (unsigned long long)count * launches;
+        h->iv_expected_dealt += (unsigned long long)count * launches;
         return CT_OK;
     };
     const int rc = run();
@@ -1572,13 +1620,13 @@ extern "C" int ct_reset(CtHandle h)
     h->render_ms = h->accum_ms = 0;
     h->launches = 0;
     h->host_paths = h->host_hits = 0;
+    h->iv_expected_dealt = 0;
     return CT_OK;
 }
 
-extern "C" int ct_tonemap(CtHandle h, float exposure, uint8_t *rgba_host, float *avg_luminance_out)
+static int tonemap_impl(CtHandle h, const float4 *mean, float exposure, uint8_t *rgba_host, float *avg_luminance_out)
 {
-    NEED(h);
-    HIPCHK(h, launch_reinhard(h->d_mean, h->scene.width, h->scene.height, exposure, h->d_colsum, h->d_avg,
+    HIPCHK(h, launch_reinhard(mean, h->scene.width, h->scene.height, exposure, h->d_colsum, h->d_avg,
                               h->d_screen, h->stream));
     if (rgba_host) {
         HIPCHK(h, hipMemcpyAsync(rgba_host, h->d_screen, (size_t)h->scene.width * h->scene.height * sizeof(uchar4),
@@ -1591,14 +1639,30 @@ extern "C" int ct_tonemap(CtHandle h, float exposure, uint8_t *rgba_host, float 
     return CT_OK;
 }
 
-extern "C" int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unconverged_pixels_out)
+extern "C" int ct_tonemap(CtHandle h, float exposure, uint8_t *rgba_host, float *avg_luminance_out)
 {
     NEED(h);
+    return tonemap_impl(h, h->d_mean, exposure, rgba_host, avg_luminance_out);
+}
+
+extern "C" int ct_tonemap_buffer(CtHandle h, const float *mean_rgba_dev, float exposure, uint8_t *rgba_host,
+                                 float *avg_luminance_out)
+{
+    NEED(h);
+    if (!mean_rgba_dev) {
+        return fail(h, CT_E_INVAL, "mean_rgba_dev is NULL");
+    }
+    return tonemap_impl(h, (const float4 *)mean_rgba_dev, exposure, rgba_host, avg_luminance_out);
+}
+
+static int converged_impl(CtHandle h, const float4 *mean, const float4 *m2, uint32_t subframes, int32_t *converged_out,
+                          uint64_t *unconverged_pixels_out)
+{
     if (!converged_out) {
         return fail(h, CT_E_INVAL, "converged_out is NULL");
     }
     const uint64_t pixels = (uint64_t)h->scene.width * h->scene.height;
-    if (h->subframes < 100) { // Camera.cpp:234-237
+    if (subframes < 100) { // Camera.cpp:234-237
         *converged_out = 0;
         if (unconverged_pixels_out) {
             *unconverged_pixels_out = pixels;
@@ -1607,7 +1671,7 @@ extern "C" int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unc
     }
     unsigned long long *d_cnt = h->d_counters + kCounterCount;
     HIPCHK(h, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), h->stream));
-    HIPCHK(h, launch_converged(h->d_mean, h->d_m2, h->subframes, pixels, d_cnt, h->stream));
+    HIPCHK(h, launch_converged(mean, m2, subframes, pixels, d_cnt, h->stream));
     unsigned long long bad = 0;
     HIPCHK(h, hipMemcpyAsync(&bad, d_cnt, sizeof bad, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1616,6 +1680,23 @@ extern "C" int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unc
         *unconverged_pixels_out = bad;
     }
     return CT_OK;
+}
+
+extern "C" int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unconverged_pixels_out)
+{
+    NEED(h);
+    return converged_impl(h, h->d_mean, h->d_m2, h->subframes, converged_out, unconverged_pixels_out);
+}
+
+extern "C" int ct_is_converged_buffers(CtHandle h, const float *mean_rgba_dev, const float *m2_rgba_dev, uint32_t subframes,
+                                       int32_t *converged_out, uint64_t *unconverged_pixels_out)
+{
+    NEED(h);
+    if (!mean_rgba_dev || !m2_rgba_dev) {
+        return fail(h, CT_E_INVAL, "mean_rgba_dev / m2_rgba_dev is NULL");
+    }
+    return converged_impl(h, (const float4 *)mean_rgba_dev, (const float4 *)m2_rgba_dev, subframes, converged_out,
+                          unconverged_pixels_out);
 }
 
 static int buffer_info(CtHandle h, int32_t which, void **ptr, size_t *bytes)
@@ -1738,6 +1819,41 @@ extern "C" int ct_counters(CtHandle h, CtCounters *out)
     return CT_OK;
 }
 
+extern "C" int ct_fetch_counters(CtHandle h, CtFetchCounters *out)
+{
+    NEED(h);
+    if (!out) {
+        return fail(h, CT_E_INVAL, "out is NULL");
+    }
+    unsigned long long c[kCounterCount];
+    HIPCHK(h, hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out->density_fetches = c[6];
+    out->inscatter_fetches = c[7];
+    return CT_OK;
+}
+
+extern "C" int ct_debug_invariants(CtHandle h, uint64_t out[8])
+{
+    NEED(h);
+    if (!out) {
+        return fail(h, CT_E_INVAL, "out is NULL");
+    }
+    unsigned long long iv[4] = { 0, 0, 0, 0 }, bad = 0;
+    HIPCHK(h, hipMemcpyAsync(iv, h->d_counters + kCounterCount + 1 + 64, sizeof iv, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&bad, h->d_counters + 8, sizeof bad, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out[0] = h->debug_invariants ? 1 : 0;
+    out[1] = h->iv_checks;
+    out[2] = h->iv_violations;
+    out[3] = bad;
+    out[4] = iv[0];
+    out[5] = iv[1];
+    out[6] = iv[2];
+    out[7] = iv[3];
+    return CT_OK;
+}
+
 extern "C" int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_ms_out, uint64_t *launches_out)
 {
     NEED(h);
@@ -1762,7 +1878,7 @@ extern "C" int ct_debug_stats(CtHandle h, uint64_t out[64])
     unsigned long long c[kStatCount];
     HIPCHK(h, hipMemcpyAsync(c, h->d_counters + kCounterCount + 1, sizeof c, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < kStatCount; i++) {
+    for (int i = 0; i < 64; i++) { // (the conservation tallies behind them: ct_debug_invariants)
         out[i] = c[i];
     }
     return CT_OK;

@@ -9,8 +9,11 @@
 namespace ct {
 
 constexpr int kTile = 8;            // pixel tile edge: 8x8 = one wave of primary rays
-constexpr int kCounterCount = 6;    // paths, box_hits, density, inscatter, scatter, capped
-constexpr int kStatCount = 64;      // scheduler diagnostics (ct_debug_stats)
+constexpr int kCounterCount = 9;    // paths, box_hits, density, inscatter, scatter, capped (the algorithm's, = the oracle's);
+                                    // then what the kernels ISSUED: density fetches, shadow-volume fetches (ct_fetch_counters),
+                                    // and the samples the accumulate kernels found without alpha == 1 (ct_debug_invariants)
+constexpr int kStatCount = 72;      // scheduler diagnostics (ct_debug_stats): [0,64) as before, [64,68) path conservation
+                                    // (samples dealt, paths resumed, results written, paths suspended; STATS kernels only)
 constexpr int kContWords = 16;      // words of a suspended path (render_persistent_kernel)
 constexpr int kContWordsDelta = 32; // the same for render_delta_kernel (its DDA state rides along)
 constexpr int kQueueFlag = 32;       // word of the queue array (its own 128-B line) that says "job list empty"
@@ -69,6 +72,7 @@ struct BatchArgs {
 struct LaunchShape {
     int blocks;
     int threads;
+    bool stats;   // launch the diagnostics build of the kernel (CT_STATS / CT_DEBUG_INVARIANTS at ct_create)
 };
 
 // Evenly split job list (no locality information): point tasks, first launches.
@@ -108,11 +112,12 @@ hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_
                                 uint32_t shard_count, hipStream_t stream);
 hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
                                    uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
-                                   uint32_t shard_count, hipStream_t stream);
+                                   uint32_t shard_count, unsigned long long *bad_samples, hipStream_t stream);
 hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, const uint32_t *pixels,
                                   uint32_t n_entries, const float4 *primary, float4 *mean, float4 *m2,
                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
-                                  uint32_t shard_index, uint32_t shard_count, hipStream_t stream);
+                                  uint32_t shard_index, uint32_t shard_count, unsigned long long *bad_samples,
+                                  hipStream_t stream);
 hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure,
                            float *column_sums, float *avg, uchar4 *screen, hipStream_t stream);
 hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,

@@ -24,7 +24,7 @@
 //                              PointRadianceTask.h, pointGeneratorCamera.cu, cloudFirstScatterMaterial.cu)
 //   mip_level_kernel, descriptor_kernel
 //                              Resources::generateMipmaps + setupHierarchicalDescriptor (DisneyDescriptor.cuh)
-//   reinhard_*                 reinhard.cu:26-84
+//   reinhard_fused_kernel      reinhard.cu:26-84 (firstPass + secondPass + applyReinhard in one launch)
 //   converged_kernel           Camera::isConverged (Camera.cpp:232-268)
 //   cdf_selftest_kernel, fetch_probe_kernel
 //                              diagnostics (exhaustive CDF inversion test, FETCH_SIZE calibration)
@@ -763,6 +763,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
     uint32_t c_dl = 0, c_il = 0, c_cap = 0; // per-lane tallies
+    // What this wave ISSUED, as opposed to what the algorithm counts (c_dl includes replayed free-space steps and the
+    // pre-walked prefix, c_il the shadow-volume footprints a lane reused): march fetches, shadow-volume fetches.
+    // Wave-uniform sums of lane counts, so they live in SGPRs and cost the lanes nothing (ct_fetch_counters).
+    uint32_t w_fetch = 0, w_nee = 0;
+    // path conservation (STATS kernels only, CT_DEBUG_INVARIANTS): samples dealt, results written
+    uint32_t iv_dealt = 0, iv_written = 0, iv_resumed = 0, iv_suspended = 0;
     uint32_t nee_key = 0xffffffffu;         // fetch_cell_cached: this lane's last shadow-volume footprint
     uint2 nee_cell = make_uint2(0u, 0u);
     // scheduler diagnostics (STATS builds only), see ct_debug_stats
@@ -794,6 +800,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             state = (int)(w3.z >> 24);
             stepv = scale3(dir, sc.sample_step);
             resumed = true;
+            if (STATS) {
+                iv_resumed += 1;
+            }
         }
     }
     const bool may_suspend = ba.cont_out != nullptr;
@@ -856,6 +865,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     const uint32_t g = job_g;
                     const uint32_t pixel = ba.pixels[g * 64u + l];
                     if (pixel != 0xffffffffu) {
+                        if (STATS) {
+                            iv_dealt += 1;
+                        }
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
                         out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + (g * 64u + l) : pixel;
@@ -897,6 +909,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                             state = ST_MARCH;
                         } else {
                             ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
+                            if (STATS) {
+                                iv_written += 1;
+                            }
                         }
                     }
                 }
@@ -919,6 +934,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 st_scat += 1;
                 st_scat_l += nb;
             }
+            bool nee_fetched = false;
             if (state == ST_BOUNCE) {
                 // The collision's back-off (cloud.cuh:99) was left for this phase: in the march phase
                 // one lane in fifteen collides per step, so its log and two divisions would run for
@@ -934,6 +950,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
                     bool nee_reused;
                     const NeeLoads nee = in_scattering_issue_lds(sc, lds.chopped, pos, dir, chopped, nee_key, nee_cell, nee_reused);
+                    nee_fetched = !nee_reused;
                     if (STATS) {
                         st_first += nee_reused ? 1u : 0u;
                     }
@@ -963,12 +980,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     finished = true;
                 }
             }
+            w_nee += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(nee_fetched));
         } else {
             // ---------------- march (getNextScatteringEvent, cloud.cuh:87-105) ----------------
             if (STATS) {
                 st_march += 1;
                 st_march_l += nm;
             }
+            w_fetch += nm; // every marching lane issues one footprint fetch per burst iteration
             // A burst of up to sc.march_burst steps per scheduler visit: the scheduler's own
             // instructions are paid once per burst, and the lanes that collide meanwhile wait for a
             // fuller scatter phase.  The burst ends early when enough lanes wait for the scatter
@@ -1029,6 +1048,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     dfree = meta & 0x80u;
                 } else if ((meta & 0x80u) == 0u && !in_box(sc, pos)) {
                     ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                    if (STATS) {
+                        iv_written += 1;
+                    }
                     if (ba.cost) {
                         atomicAdd(&ba.cost[group], work);
                         atomicMax(&ba.cost_max[group], depth);
@@ -1050,6 +1072,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             } else if (m_now < sc.burst_march_min || b_now >= sc.burst_scatter || 64u - m_now - b_now >= sc.burst_idle) {
                 break;
             }
+            w_fetch += m_now;
             if (STATS) {
                 st_march += 1;
                 st_march_l += m_now;
@@ -1058,6 +1081,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         }
         if (finished) {
             ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+            if (STATS) {
+                iv_written += 1;
+            }
             if (ba.cost) {
                 atomicAdd(&ba.cost[group], work);
                 atomicMax(&ba.cost_max[group], depth);
@@ -1088,6 +1114,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     e[2] = make_uint4(__float_as_uint(rad.z), seed, out_idx, __float_as_uint(xi));
                     e[3] = make_uint4(__float_as_uint(T), __float_as_uint(inv_maxd), depth | (dfree << 16) | ((uint32_t)state << 24), 0u);
                     state = ST_IDLE;
+                    if (STATS) {
+                        iv_suspended += 1;
+                    }
                 }
             }
         }
@@ -1105,9 +1134,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         vals[i] = v;
     }
     if (STATS) {
-        uint32_t sv[7] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1, st_skip_iters, st_first };
+        uint32_t sv[11] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1, st_skip_iters, st_first,
+                            iv_dealt, iv_resumed, iv_written, iv_suspended };
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
+        for (int i = 0; i < 11; i++) {
             uint32_t v = sv[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -1135,6 +1165,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             const unsigned long long t_end = wall_clock64();
             atomicAdd(&ba.stats[16 + min((unsigned long long)23, (t_end - t_start) / 500000ull)], 1ull);
             atomicAdd(&ba.stats[40 + min((unsigned long long)23, (t_end - (t_drained ? t_drained : t_end)) / 50000ull)], 1ull);
+            atomicAdd(&ba.stats[64], (unsigned long long)sv[7]);
+            atomicAdd(&ba.stats[65], (unsigned long long)sv[8]);
+            atomicAdd(&ba.stats[66], (unsigned long long)sv[9]);
+            atomicAdd(&ba.stats[67], (unsigned long long)sv[10]);
         }
     }
     if (lane == 0) {
@@ -1142,6 +1176,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         atomicAdd(&ba.counters[3], (unsigned long long)vals[1]);
         atomicAdd(&ba.counters[4], (unsigned long long)vals[1]); // scatter events == NEE lookups
         atomicAdd(&ba.counters[5], (unsigned long long)vals[2]);
+        atomicAdd(&ba.counters[6], (unsigned long long)w_fetch);
+        atomicAdd(&ba.counters[7], (unsigned long long)w_nee);
     }
 }
 
@@ -1460,6 +1496,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
     uint32_t c_dl = 0, c_il = 0, c_cap = 0;
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0;
+    uint32_t iv_dealt = 0, iv_written = 0, iv_resumed = 0, iv_suspended = 0; // path conservation (STATS kernels)
 
     // ---------------- path continuation, as in render_persistent_kernel (kContWordsDelta words per path) ----------------
     bool resumed = false;
@@ -1488,14 +1525,19 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             dda.by = (int32_t)w5.w;
             dda.bz = (int32_t)w6.x;
             resumed = true;
+            if (STATS) {
+                iv_resumed += 1;
+            }
         }
     }
     const bool may_suspend = ba.cont_out != nullptr;
+    // one global list: only then does "the last job has been taken" (the flag) mean that every queue is empty
+    const bool single_queue = ba.q_begin[1] == ba.n_jobs;
     uint32_t visit = 0;
 
     for (;;) {
         visit += 1;
-        if (may_suspend && !drained && sc.hint_period != 0u && (visit & (sc.hint_period - 1u)) == 0u) {
+        if (may_suspend && single_queue && !drained && sc.hint_period != 0u && (visit & (sc.hint_period - 1u)) == 0u) {
             const uint32_t empty = __builtin_amdgcn_readfirstlane(__atomic_load_n(ba.queue + kQueueFlag, __ATOMIC_RELAXED));
             if (empty != 0u && q_next == q_end) {
                 drained = true;
@@ -1533,6 +1575,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                     const uint32_t g = job_g;
                     const uint32_t pixel = ba.pixels[g * 64u + l];
                     if (pixel != 0xffffffffu) {
+                        if (STATS) {
+                            iv_dealt += 1;
+                        }
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
                         out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + (g * 64u + l) : pixel;
@@ -1579,6 +1624,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                             }
 #endif
                             ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
+                            if (STATS) {
+                                iv_written += 1;
+                            }
                         }
                     }
                 }
@@ -1691,6 +1739,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                     }
 #endif
                     ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                    if (STATS) {
+                        iv_written += 1;
+                    }
                     if (ba.cost) {
                         atomicAdd(&ba.cost[group], depth);
                         atomicMax(&ba.cost_max[group], depth);
@@ -1720,6 +1771,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             }
 #endif
             ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+            if (STATS) {
+                iv_written += 1;
+            }
             if (ba.cost) {
                 atomicAdd(&ba.cost[group], depth);
                 atomicMax(&ba.cost_max[group], depth);
@@ -1751,6 +1805,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                     e[5] = make_uint4(__float_as_uint(dda.tdelta.x), __float_as_uint(dda.tdelta.y), __float_as_uint(dda.tdelta.z), (uint32_t)dda.by);
                     e[6] = make_uint4((uint32_t)dda.bz, 0u, 0u, 0u);
                     state = ST_IDLE;
+                    if (STATS) {
+                        iv_suspended += 1;
+                    }
                 }
             }
         }
@@ -1767,9 +1824,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         vals[i] = v;
     }
     if (STATS) {
-        uint32_t sv[3] = { st_fetch, st_zero, st_skip };
+        uint32_t sv[7] = { st_fetch, st_zero, st_skip, iv_dealt, iv_resumed, iv_written, iv_suspended };
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 7; i++) {
             uint32_t v = sv[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -1787,6 +1844,10 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             atomicAdd(&ba.stats[6], (unsigned long long)sv[0]);
             atomicAdd(&ba.stats[7], (unsigned long long)sv[1]);
             atomicAdd(&ba.stats[8], (unsigned long long)sv[2]);
+            atomicAdd(&ba.stats[64], (unsigned long long)sv[3]);
+            atomicAdd(&ba.stats[65], (unsigned long long)sv[4]);
+            atomicAdd(&ba.stats[66], (unsigned long long)sv[5]);
+            atomicAdd(&ba.stats[67], (unsigned long long)sv[6]);
         }
     }
     if (lane == 0) {
@@ -1794,14 +1855,16 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         atomicAdd(&ba.counters[3], (unsigned long long)vals[1]);
         atomicAdd(&ba.counters[4], (unsigned long long)vals[1]);
         atomicAdd(&ba.counters[5], (unsigned long long)vals[2]);
+        // this kernel issues one fetch per counted lookup: cells below their lower bound are neither counted nor fetched
+        atomicAdd(&ba.counters[6], (unsigned long long)vals[0]);
+        atomicAdd(&ba.counters[7], (unsigned long long)vals[1]);
     }
 }
 
 hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream)
 {
     const dim3 grid(shape.blocks), block(shape.threads);
-    static const bool stats = getenv("CT_STATS") != nullptr;
-    if (stats) {
+    if (shape.stats) {
         switch (sc.mode) {
         case 0: hipLaunchKernelGGL((render_delta_kernel<0, true>), grid, block, 0, stream, sc, ba); break;
         case 1: hipLaunchKernelGGL((render_delta_kernel<1, true>), grid, block, 0, stream, sc, ba); break;
@@ -1820,7 +1883,7 @@ hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchSh
 LaunchShape persistent_shape(int device, bool delta)
 {
     hipDeviceProp_t prop;
-    LaunchShape s{ 1024, delta ? kDeltaThreads : 512 };
+    LaunchShape s{ 1024, delta ? kDeltaThreads : 512, false };
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         // as many blocks per CU as the kernel's registers and LDS admit: MARCH 512 threads / 40 KiB,
         // DELTA 768 threads / 64 KiB
@@ -1844,8 +1907,7 @@ LaunchShape persistent_shape(int device, bool delta)
 hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream)
 {
     const dim3 grid(shape.blocks), block(shape.threads);
-    static const bool stats = getenv("CT_STATS") != nullptr; // diagnostics build of the same kernel
-    if (stats) {
+    if (shape.stats) { // diagnostics build of the same kernel
         switch (sc.mode) {
         case 0: hipLaunchKernelGGL((render_persistent_kernel<0, true>), grid, block, 0, stream, sc, ba); break;
         case 1: hipLaunchKernelGGL((render_persistent_kernel<1, true>), grid, block, 0, stream, sc, ba); break;
@@ -1945,6 +2007,8 @@ __global__ __launch_bounds__(256) void render_simple_kernel(DevScene sc, BatchAr
     atomicAdd(&ba.counters[3], (unsigned long long)c_il);
     atomicAdd(&ba.counters[4], (unsigned long long)c_il);
     atomicAdd(&ba.counters[5], (unsigned long long)c_cap);
+    atomicAdd(&ba.counters[6], (unsigned long long)c_dl); // nothing is skipped or reused here: issued == counted
+    atomicAdd(&ba.counters[7], (unsigned long long)c_il);
 }
 
 hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_t shard_index,
@@ -2074,7 +2138,8 @@ __global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__r
                                                                float4 *__restrict__ mean, float4 *__restrict__ m2,
                                                                uint32_t first_subframe, uint32_t S, uint32_t width,
                                                                uint32_t height, uint32_t shard_index,
-                                                               uint32_t shard_count)
+                                                               uint32_t shard_count,
+                                                               unsigned long long *__restrict__ bad_samples)
 {
     const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
     const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
@@ -2087,20 +2152,26 @@ __global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__r
     const size_t pix = (size_t)y * width + x;
     const size_t plane = (size_t)width * height;
     float4 mu = mean[pix], var = m2[pix];
+    uint32_t bad = 0;
     for (uint32_t s = 0; s < S; s++) {
-        welford(mu, var, frames[s * plane + pix], first_subframe + s);
+        const float4 v = frames[s * plane + pix];
+        bad += (v.w != 1.0f) ? 1u : 0u; // every sample of this path tracer has alpha 1 (cameraCommon.cuh:29)
+        welford(mu, var, v, first_subframe + s);
     }
     mean[pix] = mu;
     m2[pix] = var;
+    if (bad != 0u && bad_samples) {
+        atomicAdd(bad_samples, (unsigned long long)bad);
+    }
 }
 
 hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
                                    uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
-                                   uint32_t shard_count, hipStream_t stream)
+                                   uint32_t shard_count, unsigned long long *bad_samples, hipStream_t stream)
 {
     const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
     hipLaunchKernelGGL(accumulate_batch_kernel, grid, block, 0, stream, frames, mean, m2, first_subframe, S, width,
-                       height, shard_index, shard_count);
+                       height, shard_index, shard_count, bad_samples);
     return hipGetLastError();
 }
 
@@ -2108,7 +2179,8 @@ hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m
 __global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__restrict__ frames, uint32_t frame_stride,
                                                               const uint32_t *__restrict__ pixels, uint32_t n_entries,
                                                               float4 *__restrict__ mean, float4 *__restrict__ m2,
-                                                              uint32_t first_subframe, uint32_t S)
+                                                              uint32_t first_subframe, uint32_t S,
+                                                              unsigned long long *__restrict__ bad_samples)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries) {
@@ -2121,7 +2193,10 @@ __global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__re
     float4 mu = mean[pix], var = m2[pix];
     // eight loads in flight per thread: a shard of an 8-GPU job has few pixels and many subframes, and one load
     // per trip round the recurrence left it waiting for memory (3.6 ms for 131 k pixels x 4096 subframes, 2.5 now; sixteen are no better)
-    uint32_t s = 0;
+    // A sample the estimator never wrote (or wrote twice into a neighbour's place) has no alpha of exactly 1: the
+    // count goes to ct_debug_invariants, and with CT_DEBUG_INVARIANTS=1 the scratch is filled with NaNs before every
+    // launch so that a lost sample cannot pass as the previous batch's.
+    uint32_t s = 0, bad = 0;
     for (; s + 8 <= S; s += 8) {
         float4 v[8];
 #pragma unroll
@@ -2130,14 +2205,20 @@ __global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__re
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
+            bad += (v[k].w != 1.0f) ? 1u : 0u;
             welford(mu, var, v[k], first_subframe + s + k);
         }
     }
     for (; s < S; s++) {
-        welford(mu, var, frames[(size_t)s * frame_stride + e], first_subframe + s);
+        const float4 v = frames[(size_t)s * frame_stride + e];
+        bad += (v.w != 1.0f) ? 1u : 0u;
+        welford(mu, var, v, first_subframe + s);
     }
     mean[pix] = mu;
     m2[pix] = var;
+    if (bad != 0u && bad_samples) {
+        atomicAdd(bad_samples, (unsigned long long)bad);
+    }
 }
 
 // Compact form, part 2: this shard's pixels whose primary ray misses the box are never rendered;
@@ -2171,11 +2252,12 @@ __global__ __launch_bounds__(256) void accumulate_miss_kernel(const float4 *__re
 hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, const uint32_t *pixels,
                                   uint32_t n_entries, const float4 *primary, float4 *mean, float4 *m2,
                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
-                                  uint32_t shard_index, uint32_t shard_count, hipStream_t stream)
+                                  uint32_t shard_index, uint32_t shard_count, unsigned long long *bad_samples,
+                                  hipStream_t stream)
 {
     if (n_entries) {
         hipLaunchKernelGGL(accumulate_list_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, stream, frames,
-                           frame_stride, pixels, n_entries, mean, m2, first_subframe, S);
+                           frame_stride, pixels, n_entries, mean, m2, first_subframe, S, bad_samples);
     }
     const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
     hipLaunchKernelGGL(accumulate_miss_kernel, grid, block, 0, stream, primary, mean, m2, first_subframe, S, width,
@@ -2193,66 +2275,85 @@ CT_DEV float luminance4(float4 c)
     return c.x * 0.265068f + c.y * 0.67023428f + c.z * 0.06409157f + c.w * 0.0f;
 }
 
-__global__ void reinhard_columns_kernel(const float4 *__restrict__ mean, uint32_t width, uint32_t height,
-                                        float *__restrict__ column_sums)
+// One launch for firstPass + secondPass + applyReinhard (the reference launches three, Camera.cpp:202-210; BASELINE.json
+// asks for a fused epilogue).  Phase 1: one thread per column sums it from y = 0 upwards.  Grid barrier (the grid has at most
+// one block per CU, so every block is resident or will be without anyone's help).  Phase 2: EVERY block adds the W
+// column sums itself, in column order, in one lane -- the same float additions as secondPass's single thread, so no
+// second barrier and no broadcast are needed.  Phase 3: applyReinhard over the pixels, grid-stride.
+__global__ __launch_bounds__(256) void reinhard_fused_kernel(const float4 *__restrict__ mean, uint32_t width, uint32_t height,
+                                                             float exposure, float *column_sums, float *__restrict__ avg_out,
+                                                             uint32_t *barrier, uchar4 *__restrict__ screen)
 {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= width) {
-        return;
-    }
+    extern __shared__ float cols[]; // width floats
+    __shared__ float avg_s;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
     const float DELTA = 0.00001f;
-    float sum = 0;
-    for (uint32_t y = 0; y < height; y++) {
-        sum += luminance4(mean[(size_t)y * width + x]) + DELTA;
+    for (uint32_t x = gtid; x < width; x += gsize) { // firstPass, reinhard.cu:29-40
+        float sum = 0;
+        for (uint32_t y = 0; y < height; y++) {
+            sum += luminance4(mean[(size_t)y * width + x]) + DELTA;
+        }
+        __hip_atomic_store(column_sums + x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    column_sums[x] = sum;
-}
-
-__global__ void reinhard_average_kernel(const float *__restrict__ column_sums, uint32_t width, uint32_t total_pixels,
-                                        float *__restrict__ avg)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(barrier, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) {
+        cols[i] = __hip_atomic_load(column_sums + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (from L2, not this CU's L1)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { // secondPass, reinhard.cu:44-55
         float result = 0;
         for (uint32_t i = 0; i < width; i++) {
-            result += column_sums[i];
+            result += cols[i];
         }
-        avg[0] = result / (float)total_pixels;
+        avg_s = result / (float)(width * height);
+        if (blockIdx.x == 0) {
+            avg_out[0] = avg_s;
+        }
+    }
+    __syncthreads();
+    const float avg = avg_s;
+    const uint32_t pixels = width * height;
+    for (uint32_t i = gtid; i < pixels; i += gsize) { // applyReinhard, reinhard.cu:59-84
+        const float4 color = mean[i];
+        const float lw = luminance4(color);
+        float ld = lw * exposure / avg;
+        ld = ld / (1.f + ld);
+        const float sc = ld / lw;
+        const float inv_gamma = 1.f / 2.2f;
+        // optix clamp(f,0,1) = fmaxf(0, fminf(f,1)): the NaN of black pixels becomes 1
+        float r = fmaxf(0.f, fminf(color.x * sc, 1.f));
+        float g = fmaxf(0.f, fminf(color.y * sc, 1.f));
+        float b = fmaxf(0.f, fminf(color.z * sc, 1.f));
+        r = ct_powf(r, inv_gamma) * 255;
+        g = ct_powf(g, inv_gamma) * 255;
+        b = ct_powf(b, inv_gamma) * 255;
+        screen[i] = make_uchar4((unsigned char)r, (unsigned char)g, (unsigned char)b, 255);
     }
 }
 
-__global__ void reinhard_apply_kernel(const float4 *__restrict__ mean, uint32_t pixels, float exposure,
-                                      const float *__restrict__ avg, uchar4 *__restrict__ screen)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pixels) {
-        return;
-    }
-    const float4 color = mean[i];
-    const float lw = luminance4(color);
-    float ld = lw * exposure / avg[0];
-    ld = ld / (1.f + ld);
-    const float sc = ld / lw;
-    const float inv_gamma = 1.f / 2.2f;
-    // optix clamp(f,0,1) = fmaxf(0, fminf(f,1)): the NaN of black pixels becomes 1
-    float r = fmaxf(0.f, fminf(color.x * sc, 1.f));
-    float g = fmaxf(0.f, fminf(color.y * sc, 1.f));
-    float b = fmaxf(0.f, fminf(color.z * sc, 1.f));
-    r = ct_powf(r, inv_gamma) * 255;
-    g = ct_powf(g, inv_gamma) * 255;
-    b = ct_powf(b, inv_gamma) * 255;
-    screen[i] = make_uchar4((unsigned char)r, (unsigned char)g, (unsigned char)b, 255);
-}
-
+// `avg` points at two words: the average luminance and the grid barrier's counter.
 hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure, float *column_sums,
                            float *avg, uchar4 *screen, hipStream_t stream)
 {
-    hipLaunchKernelGGL(reinhard_columns_kernel, dim3((width + 63) / 64), dim3(64), 0, stream, mean, width, height,
-                       column_sums);
-    hipLaunchKernelGGL(reinhard_average_kernel, dim3(1), dim3(64), 0, stream, column_sums, width, width * height,
-                       avg);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        cus = 64;
+    }
     const uint32_t pixels = width * height;
-    hipLaunchKernelGGL(reinhard_apply_kernel, dim3((pixels + 255) / 256), dim3(256), 0, stream, mean, pixels,
-                       exposure, avg, screen);
+    const uint32_t blocks = std::min<uint32_t>((uint32_t)cus, (pixels + 255u) / 256u);
+    hipError_t e = hipMemsetAsync(avg + 1, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(reinhard_fused_kernel, dim3(blocks), dim3(256), width * sizeof(float), stream, mean, width, height, exposure,
+                       column_sums, avg, (uint32_t *)(avg + 1), screen);
     return hipGetLastError();
 }
 

@@ -2,8 +2,8 @@
 
 One process per GPU (`torch.distributed`; backend "nccl" is RCCL on ROCm, "gloo" works on CPU for
 tests).  Rank r owns the 8x8-pixel tiles (tx,ty) with (tx + 3*ty) % world == r; every rank keeps
-a full-frame, zero-initialised radiance buffer and fills only its tiles, so the frame reduce is a
-plain SUM and reproduces the single-GPU image bit for bit.  torch is plumbing here (device
+full-frame, zero-initialised mean and M2 buffers and fills only its tiles, so the frame reduce is a
+plain SUM of both and reproduces the single-GPU image (and its variance) bit for bit.  torch is plumbing here (device
 memory for the staging tensor, the collective); all rendering happens in libcloudtrace.so.
 """
 from __future__ import annotations
@@ -39,9 +39,15 @@ def frame_reduce(local, dst: int = 0):
 class ShardedTracer:
     """A CloudTracer for this rank's shard plus the per-step frame reduce.
 
-    The handle's stream is a torch stream of this object, so what the library enqueues (accumulate
-    kernels, the copy of the running mean into `merged`) and what torch enqueues (the RCCL reduce of
-    `merged`) are ordered by plain stream order, with or without waiting in between."""
+    `merged` is ONE [2, H, W, 4] tensor: the running mean and M2 (Welford) of this rank's tiles, zeros elsewhere; a
+    step copies both into it and SUM-reduces it to rank 0 with one collective (tiles are disjoint, so the sum is an
+    exact merge of both).  On rank 0 `tonemap()` and `is_converged()` then run on the merged frame
+    (ct_tonemap_buffer / ct_is_converged_buffers): Reinhard's average luminance (reinhard.cu:44-55) and the count
+    of unconverged pixels (Camera.cpp:232-268) are whole-frame quantities.
+
+    The handle's stream is a torch stream of this object, so what the library enqueues (accumulate kernels, the
+    copies into `merged`) and what torch enqueues (the RCCL reduce of `merged`) are ordered by plain stream order,
+    with or without waiting in between."""
 
     def __init__(self, density: np.ndarray, params: SceneParams, rank: int, world: int, local_rank: int = 0,
                  stage_always: bool = False):
@@ -51,14 +57,23 @@ class ShardedTracer:
         params.shard_index, params.shard_count, params.device = rank, world, local_rank
         self.tracer = CloudTracer(density, params)
         self.stage = world > 1 or stage_always       # stage_always: single-rank rehearsal of the staged path
-        self.merged = torch.zeros((params.height, params.width, 4), dtype=torch.float32, device="cuda")
-        self._nbytes = self.merged.numel() * 4
+        self.merged = torch.zeros((2, params.height, params.width, 4), dtype=torch.float32, device="cuda")
+        self._nbytes = self.merged[0].numel() * 4
         self._lagging = False
+        self._merged_subframes = 0
         self.stream = None
         if self.stage:
             torch.cuda.synchronize()                 # `merged` is zeroed before another stream touches it
             self.stream = torch.cuda.Stream()
             self.tracer.set_stream(self.stream.cuda_stream)
+
+    @property
+    def merged_mean(self):
+        return self.merged[0]
+
+    @property
+    def merged_m2(self):
+        return self.merged[1]
 
     def _reduce(self):
         import torch.distributed as dist
@@ -71,13 +86,19 @@ class ShardedTracer:
             self.stream.synchronize()
             frame_reduce(self.merged, 0)
 
+    def _stage(self, wait: bool):
+        copy = self.tracer.copy_to_device if wait else self.tracer.copy_to_device_async
+        copy(_lib.CT_BUF_MEAN, self.merged[0].data_ptr(), self._nbytes)
+        copy(_lib.CT_BUF_M2, self.merged[1].data_ptr(), self._nbytes)
+        self._reduce()
+
     def step(self, first_subframe: int, count: int):
-        """Render + accumulate `count` subframes of this shard, then reduce the frame to rank 0.
-        Returns the merged running mean (valid on rank 0)."""
+        """Render + accumulate `count` subframes of this shard, then reduce [mean | M2] to rank 0.
+        Returns the merged buffer (valid on rank 0)."""
         self.tracer.render_accumulate(first_subframe, count)
+        self._merged_subframes = first_subframe + count - 1
         if self.stage:
-            self.tracer.copy_to_device(_lib.CT_BUF_MEAN, self.merged.data_ptr(), self._nbytes)
-            self._reduce()
+            self._stage(True)
             return self.merged
         return None
 
@@ -88,9 +109,9 @@ class ShardedTracer:
         batch.  `synchronize()` finishes the last batch and reduces once more; `merged` is complete on rank
         0 after it."""
         self.tracer.render_accumulate_async(first_subframe, count)
+        self._merged_subframes = first_subframe + count - 1
         if self.stage:
-            self.tracer.copy_to_device_async(_lib.CT_BUF_MEAN, self.merged.data_ptr(), self._nbytes)
-            self._reduce()
+            self._stage(False)
             self._lagging = True
             return self.merged
         return None
@@ -98,11 +119,29 @@ class ShardedTracer:
     def synchronize(self):
         self.tracer.synchronize()
         if self.stage and self._lagging:
-            self.tracer.copy_to_device(_lib.CT_BUF_MEAN, self.merged.data_ptr(), self._nbytes)
-            self._reduce()
+            self._stage(True)
             self._lagging = False
         if self.stream is not None:
             self.stream.synchronize()
+
+    # -- whole-frame quantities, on the merged frame (rank 0 of a multi-GPU job; the handle's own buffers otherwise) ----
+    def tonemap(self, exposure: float = 0.4):
+        """-> (uint8 [H,W,4] screen, average luminance) of the merged frame.  Rank 0 only when world > 1."""
+        self.synchronize()
+        if not self.stage:
+            return self.tracer.tonemap(exposure)
+        if self.rank != 0:
+            raise RuntimeError("the merged frame lives on rank 0")
+        return self.tracer.tonemap_buffer(self.merged[0].data_ptr(), exposure)
+
+    def is_converged(self):
+        """Camera::isConverged over the merged frame -> (converged, unconverged pixels).  Rank 0 only when world > 1."""
+        self.synchronize()
+        if not self.stage:
+            return self.tracer.is_converged()
+        if self.rank != 0:
+            raise RuntimeError("the merged frame lives on rank 0")
+        return self.tracer.is_converged_buffers(self.merged[0].data_ptr(), self.merged[1].data_ptr(), self._merged_subframes)
 
     def close(self):
         self.tracer.close()

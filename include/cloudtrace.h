@@ -137,6 +137,16 @@ typedef struct CtCounters {
     uint64_t depth_capped;     /* paths stopped by max_depth */
 } CtCounters;
 
+/* What the kernels actually ISSUED for the lookups above since create/ct_reset (implementation figures, not
+ * the algorithm's: the MARCH estimator replays free-space steps without a fetch, walks the part of a primary
+ * flight that is the same for every sample of a pixel once per pose, and reuses a lane's last shadow-volume
+ * footprint; every such step is still a density/inscatter lookup of the algorithm).  bench.py builds the
+ * issued-bytes roofline figure from these: 8 useful bytes per fetch. */
+typedef struct CtFetchCounters {
+    uint64_t density_fetches;   /* trilinear footprints of the density actually loaded by the estimator kernel */
+    uint64_t inscatter_fetches; /* the same for the shadow volume */
+} CtFetchCounters;
+
 typedef struct CtHandle_ *CtHandle;
 
 /* ---- lifetime --------------------------------------------------------------------- */
@@ -209,6 +219,17 @@ CT_API int ct_tonemap(CtHandle h, float exposure, uint8_t *rgba_host, float *avg
 /* Camera::isConverged, Camera.cpp:232-268, evaluated on the device.  *converged_out = 1 when
  * fewer than 500 pixels are outside the 95 % interval; *unconverged_pixels_out optional. */
 CT_API int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unconverged_pixels_out);
+
+/* The same two on caller-owned device buffers of W*H float4 each: the frame a multi-GPU reduce merged on rank 0
+ * (every shard's handle holds its own tiles and zeros elsewhere; the SUM of the shards' CT_BUF_MEAN / CT_BUF_M2 is
+ * the whole image).  reinhard.cu:44-55 sums the luminance of the WHOLE frame in a fixed order
+ * and Camera.cpp:232-268 counts over the WHOLE frame, so both run on the merged buffers, on one rank, with the
+ * single-GPU arithmetic -- not as per-shard partial sums, which would change the order of the float additions.
+ * `subframes` = samples per pixel the buffers hold.  The screen bytes go to the handle's CT_BUF_SCREEN as usual. */
+CT_API int ct_tonemap_buffer(CtHandle h, const float *mean_rgba_dev, float exposure, uint8_t *rgba_host,
+                             float *avg_luminance_out);
+CT_API int ct_is_converged_buffers(CtHandle h, const float *mean_rgba_dev, const float *m2_rgba_dev, uint32_t subframes,
+                                   int32_t *converged_out, uint64_t *unconverged_pixels_out);
 
 /* ---- radiance samples: the estimator over (point, direction) tasks -------------------------- */
 
@@ -285,6 +306,8 @@ CT_API int ct_set_subframes(CtHandle h, uint32_t count);
 
 CT_API int ct_counters(CtHandle h, CtCounters *out);
 
+CT_API int ct_fetch_counters(CtHandle h, CtFetchCounters *out);
+
 /* Milliseconds the GPU spent in the estimator kernel and in the accumulate kernel since
  * create/reset, measured with HIP events on the handle's stream, and the number of estimator
  * launches.  Any pointer may be NULL. */
@@ -297,6 +320,16 @@ CT_API int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_
 CT_API int ct_debug_stats(CtHandle h, uint64_t out[64]);
 /* Paths that ct_render_accumulate_async launches have handed to their successors so far (diagnostic). */
 CT_API int ct_debug_suspended(CtHandle h, uint64_t *paths_out);
+
+/* Path conservation and sample integrity (diagnostic).  out[0] = 1 when the handle was created with
+ * CT_DEBUG_INVARIANTS=1 in the environment: then the diagnostics build of the estimator runs, the per-sample scratch
+ * is filled with NaNs before every launch, and every entry point that waits for the batches in flight checks
+ *     samples dealt + paths resumed == results written + paths suspended,   paths resumed == paths suspended,
+ *     samples dealt == what the host handed out,   no sample without alpha == 1 reached an accumulate kernel
+ * and fails with CT_E_STATE otherwise.  out[1] = checks made, out[2] = violations, out[3] = samples without
+ * alpha 1 seen by the accumulate kernels (always counted), out[4..7] = dealt, resumed, written, suspended
+ * (0 unless out[0]). */
+CT_API int ct_debug_invariants(CtHandle h, uint64_t out[8]);
 
 /* PMC calibration probe (no handle): allocates 2^log2_lines 128-byte lines on `device`, and has one
  * thread per line issue the estimator's access pattern (two unaligned 8-byte loads at byte 13 and

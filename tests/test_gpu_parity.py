@@ -587,13 +587,57 @@ def test_sharded_tracer_staged_async_path_single_rank():
         ref.render_accumulate(first, n)
         first += n
     st.synchronize()
-    assert np.array_equal(st.merged.cpu().numpy(), ref.mean())
+    assert np.array_equal(st.merged_mean.cpu().numpy(), ref.mean())
+    assert np.array_equal(st.merged_m2.cpu().numpy(), ref.m2())
     st.step(first, 2)
     ref.render_accumulate(first, 2)
     st.synchronize()
-    assert np.array_equal(st.merged.cpu().numpy(), ref.mean())
+    assert np.array_equal(st.merged_mean.cpu().numpy(), ref.mean())
+    assert np.array_equal(st.merged_m2.cpu().numpy(), ref.m2())
+    # whole-frame quantities come from the merged buffers
+    screen, avg = st.tonemap(0.4)
+    ref_screen, ref_avg = ref.tonemap(0.4)
+    assert np.array_equal(screen, ref_screen) and avg == ref_avg
     st.close()
     ref.close()
+
+
+def test_merged_shards_tonemap_and_convergence_equal_the_single_gpu_job():
+    """What an N-GPU job does at its end, on one GPU: three shard handles render their tiles (enqueued batches),
+    their mean and M2 buffers are summed into one device buffer each (the RCCL reduce's arithmetic: foreign
+    pixels are exactly 0), and rank 0's handle tonemaps the merged frame and counts its unconverged pixels
+    (ct_tonemap_buffer / ct_is_converged_buffers).  Screen bytes, average luminance and the count must equal
+    the single-GPU job's -- which a shard's own buffers cannot give (its foreign pixels are black and count as
+    converged)."""
+    torch = pytest.importorskip("torch")
+    tex = sphere_volume(40, radius=0.42, seed=21)
+    w, h, spp = 96, 72, 120
+    kw = dict(mode=0, cloud_size_m=3000.0, max_depth=200)
+    whole = ds.CloudTracer(tex, width=w, height=h, **kw)
+    whole.render_accumulate(1, spp)
+    want_screen, want_avg = whole.tonemap(0.4)
+    want_conv = whole.is_converged()
+    world = 3
+    merged = torch.zeros((2, h, w, 4), dtype=torch.float32, device="cuda")
+    shards = []
+    for r in range(world):
+        sh = ds.CloudTracer(tex, width=w, height=h, shard_index=r, shard_count=world, **kw)
+        sh.render_accumulate_async(1, 50)
+        sh.render_accumulate_async(51, spp - 50)
+        merged[0] += torch.from_numpy(sh.mean()).cuda()
+        merged[1] += torch.from_numpy(sh.m2()).cuda()
+        shards.append(sh)
+    torch.cuda.synchronize()
+    assert np.array_equal(merged[0].cpu().numpy(), whole.mean()) and np.array_equal(merged[1].cpu().numpy(), whole.m2())
+    screen, avg = shards[0].tonemap_buffer(merged[0].data_ptr(), 0.4)
+    conv = shards[0].is_converged_buffers(merged[0].data_ptr(), merged[1].data_ptr(), spp)
+    assert np.array_equal(screen, want_screen) and avg == want_avg
+    assert conv == want_conv and want_conv[1] > 0
+    own_screen, own_avg = shards[0].tonemap(0.4)              # a shard's own view is a different picture
+    assert own_avg != want_avg and shards[0].is_converged()[1] < want_conv[1]
+    for sh in shards:
+        sh.close()
+    whole.close()
 
 
 def test_error_behaviour_of_the_newer_entry_points():
@@ -864,13 +908,17 @@ def test_randomized_continuation_soak():
     assert suspended > 100000
 
 
-def test_scheduler_knobs_never_change_a_result(monkeypatch):
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_scheduler_knobs_never_change_a_result(monkeypatch, estimator):
     """Every CT_* knob only changes the schedule (burst lengths, regeneration and scatter thresholds, per-XCD
     queues, blocks per CU, the pre-walked prefix, path continuation, the queue-empty hint): mean, M2 and the
-    counters of enqueued batches must be identical under any of them."""
+    counters of enqueued batches must be identical under any of them -- for both estimators (round 1 ran MARCH
+    only, and the DELTA kernel lost the jobs of seven of the eight per-XCD queues in enqueued batches: it read the
+    "last job taken" flag as "every queue is empty").  The runs under a knob also arm CT_DEBUG_INVARIANTS: NaN-filled
+    scratch, path conservation, no sample without alpha 1."""
     tex = sphere_volume(44, radius=0.38, seed=41)
     w, h = 200, 144
-    kw = dict(mode=0, cloud_size_m=20000.0, max_depth=500)
+    kw = dict(mode=0, cloud_size_m=20000.0, max_depth=500, estimator=estimator)
 
     def run():
         tr = ds.CloudTracer(tex, width=w, height=h, **kw)
@@ -878,10 +926,17 @@ def test_scheduler_knobs_never_change_a_result(monkeypatch):
         tr.render_accumulate_async(6, 3)
         tr.render_accumulate_async(9, 6)
         out = (tr.mean(), tr.m2(), tr.counters())
+        iv = tr.debug_invariants()
+        assert iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+        if iv["armed"]:
+            assert iv["checks"] >= 1 and iv["dealt"] == iv["written"] > 0 and iv["resumed"] == iv["suspended"], iv
         tr.close()
         return out
 
     base = run()
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    armed = run()
+    assert np.array_equal(armed[0], base[0]) and np.array_equal(armed[1], base[1]) and armed[2] == base[2]
     settings = [
         {"CT_MARCH_BURST": "1"}, {"CT_MARCH_BURST": "3", "CT_BURST_SCATTER": "5", "CT_BURST_IDLE": "7"},
         {"CT_MARCH_BURST": "64", "CT_BURST_SCATTER": "65", "CT_BURST_IDLE": "65"},
@@ -910,3 +965,66 @@ def test_multi_gpu_step_on_the_rccl_backend_single_rank():
     script = Path(__file__).resolve().parents[1] / "tools" / "nccl_single_rank_check.py"
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "NCCL single-rank check: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_xcd_queues_with_enqueued_batches_lose_no_job(monkeypatch, estimator):
+    """Per-XCD job queues (the default for volumes >= 768^3, CT_XCD_QUEUES=1 anywhere) with enqueued batches whose
+    paths cross launches, invariants armed: results and every counter equal the synchronous single-queue run's and
+    the oracle's on a window.  This is the configuration in which the DELTA kernel dropped jobs in round 1."""
+    tex = sphere_volume(56, radius=0.4, seed=5)
+    w, h = 320, 240
+    kw = dict(mode=0, cloud_size_m=20000.0, max_depth=800, estimator=estimator)
+    ref = ds.CloudTracer(tex, width=w, height=h, **kw)
+    ref.render_accumulate(1, 6)
+    ref.render_accumulate(7, 10)
+    want = (ref.mean(), ref.m2(), ref.counters())
+    ins = ref.inscatter()
+    ref.close()
+    monkeypatch.setenv("CT_XCD_QUEUES", "1")
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    tr = ds.CloudTracer(tex, width=w, height=h, **kw)
+    tr.render_accumulate_async(1, 6)
+    tr.render_accumulate_async(7, 10)
+    got = (tr.mean(), tr.m2(), tr.counters())
+    iv = tr.debug_invariants()
+    assert iv["armed"] == 1 and iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+    assert iv["dealt"] == iv["written"] == want[2]["box_hits"] and iv["resumed"] == iv["suspended"] > 0, iv
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    orc = O.Oracle(tex, w, h, fast=True, estimator=estimator, inscatter=ins, cloud_size_m=20000.0, max_depth=800)
+    win = (150, 110, 166, 126)
+    ref_mean, ref_m2 = orc.render(16, window=win)
+    x0, y0, x1, y1 = win
+    assert np.array_equal(got[0][y0:y1, x0:x1], ref_mean[y0:y1, x0:x1])
+    assert np.array_equal(got[1][y0:y1, x0:x1], ref_m2[y0:y1, x0:x1])
+    tr.close()
+
+
+def test_fetch_counters_are_what_the_kernels_issue(monkeypatch):
+    """ct_fetch_counters: the MARCH estimator issues fewer fetches than the algorithm counts lookups (free-space
+    replay, pre-walked prefix, reused shadow-volume footprints) and exactly as many as its diagnostics build tallies
+    lane by lane; DELTA and the one-thread-per-pixel kernel issue one fetch per lookup."""
+    tex = ds.make_procedural_cloud(96)
+    w, h = 160, 128
+    monkeypatch.setenv("CT_STATS", "1")
+    tr = ds.CloudTracer(tex, width=w, height=h)
+    tr.render_accumulate(1, 40)
+    tr.render_accumulate_async(41, 24)
+    c, f, st = tr.counters(), tr.fetch_counters(), tr.debug_stats()
+    tr.close()
+    monkeypatch.delenv("CT_STATS")
+    assert 0 < f["density_fetches"] < c["density_lookups"]
+    assert 0 < f["inscatter_fetches"] <= c["inscatter_lookups"]
+    assert f["density_fetches"] == st["fetched_steps"]
+    assert f["inscatter_fetches"] == c["inscatter_lookups"] - st["nee_footprints_reused"]
+    plain = ds.CloudTracer(tex, width=w, height=h)          # the production build counts the same
+    plain.render_accumulate(1, 40)
+    plain.render_accumulate_async(41, 24)
+    assert plain.fetch_counters() == f and plain.counters() == c
+    plain.close()
+    for kw in (dict(estimator=1), dict(flags=_lib.CT_FLAG_SIMPLE_KERNEL)):
+        t = ds.CloudTracer(tex, width=w, height=h, **kw)
+        t.render_accumulate(1, 4)
+        c, f = t.counters(), t.fetch_counters()
+        assert f == {"density_fetches": c["density_lookups"], "inscatter_fetches": c["inscatter_lookups"]}, kw
+        t.close()

@@ -14,7 +14,7 @@ fi
 for C in ${CONFIGS:-1:65:65 4:16:16}; do
   IFS=: read B SC ID <<< "$C"
   echo "== burst $B scatter $SC idle $ID ${EXTRA_ENV}" >> gpurun_out/burst.log
-  env CT_MARCH_BURST=$B CT_BURST_SCATTER=$SC CT_BURST_IDLE=$ID ${EXTRA_ENV} timeout -k 10 200 python bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --spp-per-step ${S:-128} 2>gpurun_out/burst_stderr.log | python3 -c "
+  env CT_MARCH_BURST=$B CT_BURST_SCATTER=$SC CT_BURST_IDLE=$ID ${EXTRA_ENV} timeout -k 10 200 python bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-pmc-traffic --spp-per-step ${S:-128} 2>gpurun_out/burst_stderr.log | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

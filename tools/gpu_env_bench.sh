@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 IFS='|' read -ra RUNS <<< "${ENVS:-X=0}"
 for E in "${RUNS[@]}"; do
   echo "== $E ${ARGS:-}" >> gpurun_out/envbench.log
-  env $E timeout -k 10 300 python bench.py --steps ${STEPS:-4} --warmup 1 --no-cpu-baseline ${ARGS:-} 2>/dev/null | python3 -c "
+  env $E timeout -k 10 300 python bench.py --steps ${STEPS:-4} --warmup 1 --no-cpu-baseline --no-pmc-traffic ${ARGS:-} 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 : > gpurun_out/sweep.log
 for S in ${SWEEP:-16 64}; do
   echo "== spp-per-step $S ${EXTRA_ENV}" >> gpurun_out/sweep.log
-  env ${EXTRA_ENV} timeout -k 10 300 python bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --spp-per-step $S 2>/dev/null | python3 -c "
+  env ${EXTRA_ENV} timeout -k 10 300 python bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-pmc-traffic --spp-per-step $S 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

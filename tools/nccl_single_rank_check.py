@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The multi-GPU step with the real RCCL backend on one rank (a second GPU is not available to the tests):
 process group "nccl" of world size 1, ShardedTracer with the staged path forced, enqueued steps + the
-collective on the shared torch stream; the staging tensor must hold the running mean afterwards."""
+collective on the shared torch stream; the staging tensor must hold the running mean and M2 afterwards."""
 import os
 import sys
 from pathlib import Path
@@ -31,9 +31,10 @@ for n in (3, 5, 2, 4):
 st.synchronize()
 dist.barrier()
 torch.cuda.synchronize()
-ok = np.array_equal(st.merged.cpu().numpy(), ref.mean())
+ok = np.array_equal(st.merged_mean.cpu().numpy(), ref.mean()) and np.array_equal(st.merged_m2.cpu().numpy(), ref.m2())
 st.step(first, 2); ref.render_accumulate(first, 2); st.synchronize()
-ok = ok and np.array_equal(st.merged.cpu().numpy(), ref.mean())
+ok = ok and np.array_equal(st.merged_mean.cpu().numpy(), ref.mean()) and np.array_equal(st.merged_m2.cpu().numpy(), ref.m2())
+ok = ok and st.is_converged() == ref.is_converged()
 t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 ok = ok and float(t.item()) == 1.5

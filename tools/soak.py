@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Soak run of the randomized differential test's generator: many random scenes and batch patterns, HIP path
 vs oracle, bit for bit.  python tools/soak.py <seed> <cases>"""
+import os
 import sys
 from pathlib import Path
+os.environ.setdefault("CT_DEBUG_INVARIANTS", "1")   # NaN-filled scratch + path conservation, checked by the library itself
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import torch  # noqa: F401  (first: see tests/conftest.py)
@@ -16,17 +18,27 @@ bad = 0
 for case in range(cases):
     kw, eye = _random_scene(rng)
     tex = kw.pop("tex"); w, h = kw.pop("width"), kw.pop("height")
+    # per-XCD job queues in a third of the cases (read at ct_create)
+    os.environ["CT_XCD_QUEUES"] = "1" if rng.random() < 0.33 else "0"
     tr, orc = make_pair(tex, w, h, **kw)
     U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
     tr.set_camera(eye, U, V, W); orc.set_camera(eye, U, V, W)
     first = 1
-    pattern = []
-    for n in rng.integers(1, 5, 4):
-        a = bool(rng.random() < 0.6)
-        (tr.render_accumulate_async if a else tr.render_accumulate)(first, int(n))
-        pattern.append((int(n), a)); first += int(n)
-    mean, m2 = orc.render(first - 1)
-    got_mean, got_m2, got_counters = tr.mean(), tr.m2(), tr.counters()
+    pattern = [(int(n), bool(rng.random() < 0.6)) for n in rng.integers(1, 5, 4)]
+    try:
+        for n, a in pattern:
+            (tr.render_accumulate_async if a else tr.render_accumulate)(first, n)
+            first += n
+        got_mean, got_m2, got_counters = tr.mean(), tr.m2(), tr.counters()
+    except ds.CloudTraceError as e:
+        bad += 1
+        print(f"INVARIANT seed {seed} case {case}: {e}; dims {tex.shape[::-1]} {w}x{h} {kw} eye {eye} batches {pattern} "
+              f"xcd {os.environ['CT_XCD_QUEUES']}", flush=True)
+        tr.close()
+        continue
+    mean, m2 = orc.render(sum(n for n, _ in pattern))
+    iv = tr.debug_invariants()
+    assert iv["armed"] == 1 and iv["checks"] > 0, iv
     ok = np.array_equal(got_mean, mean) and np.array_equal(got_m2, m2) and got_counters == orc.counters.as_dict()
     if not ok:
         bad += 1

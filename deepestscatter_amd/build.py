@@ -20,7 +20,7 @@ LIB = PKG / "libcloudtrace.so"
 
 SOURCES = ["ct_kernels.hip", "ct_api.cpp", "ct_host.cpp"]
 HEADERS = [CSRC / "ct_device.hpp", CSRC / "ct_internal.hpp", ROOT / "include" / "cloudtrace.h",
-           ROOT / "include" / "ct_fmath.h"]
+           ROOT / "include" / "ct_fmath.h", PKG / "host" / "VdbReader.h"]
 
 # -ffp-contract=off is part of the numeric contract (include/ct_fmath.h): results must be
 # bit-identical to the CPU oracle, so no implicit FMA contraction and no fast-math.
@@ -49,7 +49,7 @@ CLI = HOST / "cloudtrace"
 
 def build_cli(force: bool = False, verbose: bool = False) -> Path:
     """The C++ host mirror of the reference's scene classes + headless CLI (g++, links the C ABI)."""
-    srcs = [HOST / "main.cpp", HOST / "Cameras.h", HOST / "Scene.h", HOST / "SceneDescription.h",
+    srcs = [HOST / "main.cpp", HOST / "Cameras.h", HOST / "Scene.h", HOST / "SceneDescription.h", HOST / "VdbReader.h",
             ROOT / "include" / "cloudtrace.h"]
     if not force and CLI.exists() and LIB.exists() and all(s.stat().st_mtime <= CLI.stat().st_mtime for s in srcs + [LIB]):
         return CLI
@@ -64,7 +64,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> Path:
 def build(force: bool = False, verbose: bool = False) -> Path:
     if force or needs_build():
         # CT_EXTRA_FLAGS: e.g. -DCT_DEBUG_BOUNDS (device-side index checks that report instead of faulting)
-        cmd = [hipcc(), *FLAGS, *os.environ.get("CT_EXTRA_FLAGS", "").split(), "-o", str(LIB), *[str(CSRC / s) for s in SOURCES]]
+        cmd = [hipcc(), *FLAGS, *os.environ.get("CT_EXTRA_FLAGS", "").split(), "-o", str(LIB), *[str(CSRC / s) for s in SOURCES], "-lz"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=str(CSRC))

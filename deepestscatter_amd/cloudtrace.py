@@ -72,6 +72,22 @@ def quantize_volume(grid: np.ndarray) -> np.ndarray:
     return out
 
 
+def load_vdb(path) -> np.ndarray:
+    """Resources::loadVolumeBuffer for a .vdb file (Resources.cpp:82-143; ct_load_vdb): -> uint8 [Z,Y,X] texture."""
+    L = _lib.load()
+    dims = np.zeros(3, np.uint32)
+    n = C.c_size_t(0)
+    err = C.create_string_buffer(512)
+    rc = L.ct_load_vdb(str(path).encode(), _p(dims), None, 0, C.byref(n), err, 512)
+    if rc != _lib.CT_OK:
+        raise _lib.CloudTraceError(rc, err.value.decode("utf-8", "replace"))
+    out = np.empty((int(dims[2]), int(dims[1]), int(dims[0])), np.uint8)
+    rc = L.ct_load_vdb(str(path).encode(), _p(dims), _p(out), out.nbytes, C.byref(n), err, 512)
+    if rc != _lib.CT_OK:
+        raise _lib.CloudTraceError(rc, err.value.decode("utf-8", "replace"))
+    return out
+
+
 def generate_mipmaps(level0: np.ndarray) -> list[np.ndarray]:
     """Resources::generateMipmaps (Resources.cpp:169-209): list of uint8 [z,y,x] levels."""
     level0 = np.ascontiguousarray(level0, np.uint8)
@@ -326,6 +342,14 @@ class CloudTracer:
         out = np.zeros(8, np.uint64)
         check(self.L.ct_debug_invariants(self.h, _p(out)), self.h)
         names = ["armed", "checks", "violations", "samples_without_alpha_1", "dealt", "resumed", "written", "suspended"]
+        return {n: int(v) for n, v in zip(names, out)}
+
+    def debug_memory(self) -> dict:
+        """Bytes of the volume representations on the device (ct_debug_memory)."""
+        out = np.zeros(8, np.uint64)
+        check(self.L.ct_debug_memory(self.h, _p(out)), self.h)
+        names = ["raw_texture", "density_bricks", "inscatter_bricks", "march_bricks_dense", "march_bricks_stored", "sparse",
+                 "row_table", "coarse_clearance"]
         return {n: int(v) for n, v in zip(names, out)}
 
     def kernel_time(self):

@@ -34,6 +34,9 @@ struct CtHandle_ {
     // device memory
     uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr, *d_majorant = nullptr, *d_maj_cells = nullptr, *d_maj_codes = nullptr;
     uint8_t *d_dbricks = nullptr, *d_ibricks = nullptr, *d_mbricks = nullptr;
+    uint2 *d_mrows = nullptr;          // sparse march bricks: extent of every brick row (DevScene::m_rows)
+    uint8_t *d_mcoarse = nullptr;      // ... and the clearance of the coarse cells outside the extents
+    size_t mbricks_dense_bytes = 0, mbricks_bytes = 0;
     uint8_t *d_pyramid = nullptr;     // density mip pyramid, built on first use (ct_collect_descriptors)
     MipPyramid pyramid{};
     float *d_mie = nullptr, *d_chopped = nullptr, *d_cdf = nullptr;
@@ -246,7 +249,7 @@ static void release(CtHandle h)
     if (h->stream) {
         hipStreamSynchronize(h->stream);
     }
-    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
+    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->slots[0].queue, h->slots[1].queue, h->slots[0].cont, h->slots[1].cont, h->d_cont_count, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg };
     for (void *p : ptrs) {
@@ -542,7 +545,9 @@ static int create_impl(const CtScene *s, CtHandle h)
             return fail(h, CT_E_INVAL, "volume too large for 32-bit brick indices");
         }
         uint8_t *tmp_a = nullptr, *tmp_b = nullptr;
-        HIPCHK(h, dmalloc(&h->d_mbricks, (size_t)(mgx * bgy * bgz) * 128));
+        const size_t dense_bytes = (size_t)(mgx * bgy * bgz) * 128;
+        h->mbricks_dense_bytes = h->mbricks_bytes = dense_bytes;
+        HIPCHK(h, dmalloc(&h->d_mbricks, dense_bytes));
         HIPCHK(h, dmalloc(&tmp_a, texels));
         if (hipMalloc(&tmp_b, texels) != hipSuccess) {
             hipFree(tmp_a);
@@ -551,10 +556,85 @@ static int create_impl(const CtScene *s, CtHandle h)
         const hipError_t e = launch_build_mbricks(h->d_density, nx, ny, nz, mbias, bbias, (int)mgx, (int)bgy, (int)bgz,
                                                   tmp_a, tmp_b, h->d_mbricks, h->stream);
         const hipError_t e2 = hipStreamSynchronize(h->stream);
+        // Sparse storage (BASELINE.json configs[4]: "1024^3 sparse brick-compressed density"): for volumes of 768^3
+        // texels and more, where the dense array (2.9 GB at 1024^3) is far beyond every cache; CT_SPARSE=0/1 overrides.
+        bool sparse = (uint64_t)nx * ny * nz >= 768ull * 768ull * 768ull;
+        if (const char *env = getenv("CT_SPARSE")) {
+            sparse = atoi(env) != 0;
+        }
+        int src = CT_OK;
+        if (e == hipSuccess && e2 == hipSuccess && sparse && s->estimator == CT_EST_MARCH) {
+            src = [&]() -> int {
+                const size_t rows = (size_t)(bgy * bgz);
+                uint32_t *d_x0 = nullptr, *d_x1 = nullptr;
+                uint8_t *compact = nullptr;
+                auto cleanup = [&]() {
+                    for (void *q : { (void *)d_x0, (void *)d_x1 }) {
+                        if (q) {
+                            hipFree(q);
+                        }
+                    }
+                };
+                auto body = [&]() -> int {
+                    HIPCHK(h, dmalloc(&d_x0, rows));
+                    HIPCHK(h, dmalloc(&d_x1, rows));
+                    HIPCHK(h, hipMemsetAsync(d_x0, 0xff, rows * sizeof(uint32_t), h->stream));
+                    HIPCHK(h, hipMemsetAsync(d_x1, 0, rows * sizeof(uint32_t), h->stream));
+                    HIPCHK(h, launch_mbrick_extent(h->d_mbricks, (int)mgx, (int)bgy, (int)bgz, d_x0, d_x1, h->stream));
+                    std::vector<uint32_t> x0(rows), x1(rows);
+                    HIPCHK(h, hipMemcpyAsync(x0.data(), d_x0, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(h, hipMemcpyAsync(x1.data(), d_x1, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(h, hipStreamSynchronize(h->stream));
+                    std::vector<uint2> ri(rows);
+                    uint64_t lines = 0;
+                    for (size_t r = 0; r < rows; r++) {
+                        const uint32_t cnt = x1[r] > x0[r] ? x1[r] - x0[r] : 0u;
+                        ri[r] = make_uint2((uint32_t)lines, cnt ? (x0[r] | (cnt << 16)) : 0u);
+                        lines += cnt;
+                    }
+                    if (lines >= (1ull << 32)) {
+                        return fail(h, CT_E_INVAL, "volume too large for 32-bit brick indices");
+                    }
+                    HIPCHK(h, dmalloc(&h->d_mrows, rows));
+                    HIPCHK(h, hipMemcpyAsync(h->d_mrows, ri.data(), rows * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+                    HIPCHK(h, dmalloc(&compact, std::max<size_t>((size_t)lines, 1) * 128));
+                    HIPCHK(h, launch_mbrick_compact(h->d_mbricks, (int)mgx, (int)bgy, (int)bgz, h->d_mrows, compact, h->stream));
+                    // clearance of the cells outside the extents: cubic cells of 8 texels over the brick grid's texel range
+                    const int cshift = 3;
+                    const int64_t cgx = (4 * bgx + 7) >> cshift, cgy = (4 * bgy + 7) >> cshift, cgz = (4 * bgz + 7) >> cshift;
+                    HIPCHK(h, dmalloc(&h->d_mcoarse, (size_t)(cgx * cgy * cgz)));
+                    HIPCHK(h, launch_coarse_clearance(tmp_b, nx, ny, nz, bbias, cshift, (int)cgx, (int)cgy, (int)cgz, h->d_mcoarse,
+                                                      h->stream));
+                    HIPCHK(h, hipStreamSynchronize(h->stream)); // `ri` dies at scope exit; the dense array is freed below
+                    HIPCHK(h, hipFree(h->d_mbricks));
+                    h->d_mbricks = compact;
+                    compact = nullptr;
+                    h->mbricks_bytes = (size_t)lines * 128;
+                    d.m_rows = h->d_mrows;
+                    d.m_coarse = h->d_mcoarse;
+                    d.m_cshift = cshift;
+                    d.m_cgx = (int32_t)cgx;
+                    d.m_cgxy = (int32_t)(cgx * cgy);
+                    return CT_OK;
+                };
+                const int rc = body();
+                if (rc != CT_OK) {
+                    hipStreamSynchronize(h->stream);
+                    if (compact) {
+                        hipFree(compact);
+                    }
+                }
+                cleanup();
+                return rc;
+            }();
+        }
         hipFree(tmp_a);
         hipFree(tmp_b);
         HIPCHK(h, e);
         HIPCHK(h, e2);
+        if (src != CT_OK) {
+            return src;
+        }
         d.mbricks = h->d_mbricks;
         d.m_bias_x = mbias;
         d.m_gx = (int32_t)mgx;
@@ -1881,6 +1961,24 @@ extern "C" int ct_debug_stats(CtHandle h, uint64_t out[64])
     for (int i = 0; i < 64; i++) { // (the conservation tallies behind them: ct_debug_invariants)
         out[i] = c[i];
     }
+    return CT_OK;
+}
+
+extern "C" int ct_debug_memory(CtHandle h, uint64_t out[8])
+{
+    NEED(h);
+    if (!out) {
+        return fail(h, CT_E_INVAL, "out is NULL");
+    }
+    const size_t brick_bytes = (size_t)h->dev.brick_gxy * (size_t)h->dev.brick_gz * 128;
+    out[0] = h->volume_bytes;
+    out[1] = brick_bytes;                 // density apron bricks
+    out[2] = brick_bytes;                 // shadow-volume apron bricks
+    out[3] = h->mbricks_dense_bytes;
+    out[4] = h->mbricks_bytes;
+    out[5] = h->dev.m_rows ? 1 : 0;
+    out[6] = h->dev.m_rows ? (size_t)h->dev.brick_gy * h->dev.brick_gz * sizeof(uint2) : 0;
+    out[7] = h->dev.m_rows ? (size_t)h->dev.m_cgxy * (size_t)((4 * h->dev.brick_gz + 7) >> h->dev.m_cshift) : 0;
     return CT_OK;
 }
 

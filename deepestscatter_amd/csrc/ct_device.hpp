@@ -79,6 +79,16 @@ struct DevScene {
     // bit 7 = "interior" for the row's bases (1 <= base <= N-3 on every axis: isInBox holds for
     // every position based there and for a scatter position backed off from it).
     const uint8_t *mbricks;
+    // Sparse march bricks (volumes of 768^3 texels and more, CT_SPARSE): of every brick row (by, bz) only the bricks
+    // between its first and its last one that holds a non-zero texel are stored, one row after the other.
+    // m_rows[bz * brick_gy + by] = (line index of the row's first stored brick, x0 | count << 16).  A footprint based
+    // in a brick outside its row's extent is all zero by construction; its clearance and "interior" flag come
+    // from m_coarse, one byte (same format as a row's meta byte) per cubic cell of 2^m_cshift texels: the minimum over
+    // the cell's base texels.  Both tables are small (0.5 MB + 2.5 MB at 1024^3 against 2.9 GB of dense bricks) and
+    // stay in L2, so a landing in open space costs no line fill.  m_rows == NULL: dense array, direct addressing.
+    const uint2 *m_rows;
+    const uint8_t *m_coarse;
+    int32_t m_cshift, m_cgx, m_cgxy;
     // The DELTA estimator's majorants: one byte per cubic cell of 2^mc_shift texels over the texel range
     // [-brick_bias, n + brick_bias) per axis, x-fastest.  mc_shift is the smallest value >= 2 for which the grid
     // has at most kMajCellsMax cells, so that every block keeps the whole grid in LDS and a flight crosses cells
@@ -214,6 +224,7 @@ CT_DEV uint2 load_footprint_meta(const DevScene &sc, const uint8_t *bricks, int3
 }
 
 // Footprint + row meta byte from the 3x4x4 march bricks (see DevScene::mbricks): two loads.
+template <bool SPARSE>
 CT_DEV uint2 load_footprint_m(const DevScene &sc, int32_t ix, int32_t iy, int32_t iz, uint32_t &meta)
 {
     const uint32_t x = (uint32_t)(ix + sc.m_bias_x), y = (uint32_t)(iy + sc.brick_bias), z = (uint32_t)(iz + sc.brick_bias);
@@ -229,6 +240,18 @@ CT_DEV uint2 load_footprint_m(const DevScene &sc, int32_t ix, int32_t iy, int32_
     }
 #endif
     const uint8_t *p = sc.mbricks + (((size_t)brick << 7) | local);
+    if (SPARSE) {
+        const uint32_t row = __umul24(z >> 2, (uint32_t)sc.brick_gy) + (y >> 2);
+        const uint2 ri = sc.m_rows[row];
+        const uint32_t rel = bx - (ri.y & 0xffffu);
+        if (rel >= (ri.y >> 16)) {
+            // outside the row's stored extent: zero footprint; clearance and interior flag of the coarse cell
+            const uint32_t cx = (uint32_t)(ix + sc.brick_bias) >> sc.m_cshift;
+            meta = sc.m_coarse[__umul24(z >> sc.m_cshift, (uint32_t)sc.m_cgxy) + __umul24(y >> sc.m_cshift, (uint32_t)sc.m_cgx) + cx];
+            return make_uint2(0u, 0u);
+        }
+        p = sc.mbricks + (((size_t)(ri.x + rel) << 7) | local);
+    }
     uint2 a, c;
     __builtin_memcpy(&a, p, 8);       // t_lx, t_lx+1 of row ly at bytes 0,1; of row ly+1 at 5,6; M at 4-lx
     __builtin_memcpy(&c, p + 25, 8);  // the same one z-slice up
@@ -305,10 +328,11 @@ CT_DEV uint2 fetch_cell_cached(const DevScene &sc, const uint8_t *bricks, f3 p, 
     return cached;
 }
 
+template <bool SPARSE>
 CT_DEV uint2 fetch_cell_m(const DevScene &sc, f3 p, uint32_t &meta)
 {
     const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
-    return load_footprint_m(sc, floor_to_int(x), floor_to_int(y), floor_to_int(z), meta);
+    return load_footprint_m<SPARSE>(sc, floor_to_int(x), floor_to_int(y), floor_to_int(z), meta);
 }
 
 CT_DEV float filter_at(const DevScene &sc, uint2 cell, f3 p)

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/cloudtrace.h"
+#include "../host/VdbReader.h"
 
 namespace {
 
@@ -240,4 +241,46 @@ extern "C" int ct_make_procedural_cloud(uint32_t n, uint32_t seed, uint8_t *tex)
     const int rc = ct_quantize_volume(grid, pd, tex);
     delete[] grid;
     return rc;
+}
+
+
+// Resources::loadVolumeBuffer for a .vdb file (Resources.cpp:82-143) without OpenVDB: host/VdbReader.h.
+extern "C" int ct_load_vdb(const char *path, uint32_t dims_out[3], uint8_t *texture_host_out, size_t capacity, size_t *bytes_out,
+                           char *error_out, size_t error_capacity)
+{
+    auto report = [&](const char *msg) {
+        if (error_out && error_capacity) {
+            std::strncpy(error_out, msg, error_capacity - 1);
+            error_out[error_capacity - 1] = 0;
+        }
+    };
+    if (!path || !dims_out) {
+        report("path / dims_out is NULL");
+        return CT_E_INVAL;
+    }
+    try {
+        std::vector<uint8_t> tex;
+        std::array<uint32_t, 3> dims{};
+        DeepestScatter::vdb::loadVolumeTexture(path, tex, dims);
+        dims_out[0] = dims[0];
+        dims_out[1] = dims[1];
+        dims_out[2] = dims[2];
+        if (bytes_out) {
+            *bytes_out = tex.size();
+        }
+        if (texture_host_out) {
+            if (capacity < tex.size()) {
+                report("capacity too small");
+                return CT_E_INVAL;
+            }
+            std::memcpy(texture_host_out, tex.data(), tex.size());
+        }
+        return CT_OK;
+    } catch (const std::bad_alloc &) {
+        report("out of host memory");
+        return CT_E_NOMEM;
+    } catch (const std::exception &e) {
+        report(e.what());
+        return CT_E_INVAL;
+    }
 }

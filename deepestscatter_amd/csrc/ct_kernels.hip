@@ -189,6 +189,7 @@ __global__ void build_mbricks_kernel(const uint8_t *__restrict__ t, const uint8_
     }
 }
 
+// (leaves the distance volume in tmp_b: launch_coarse_clearance reads it)
 hipError_t launch_build_mbricks(const uint8_t *texels, int nx, int ny, int nz, int bias_x, int bias, int gx, int gy,
                                 int gz, uint8_t *tmp_a, uint8_t *tmp_b, uint8_t *bricks, hipStream_t stream)
 {
@@ -203,6 +204,94 @@ hipError_t launch_build_mbricks(const uint8_t *texels, int nx, int ny, int nz, i
     const int bb = (int)std::min<int64_t>((total + threads - 1) / threads, 65536 * 4);
     hipLaunchKernelGGL(build_mbricks_kernel, dim3(bb), dim3(threads), 0, stream, texels, tmp_b, nx, ny, nz, bias_x, bias,
                        bricks, gx, gy, gz);
+    return hipGetLastError();
+}
+
+// ---- sparse march bricks (DevScene::m_rows, m_coarse) ------------------------------------------------------
+// Extent of every brick row: the bricks from the first to the last one with a non-zero texel byte (meta bytes, at
+// lx == 4, do not count).  row_x0 starts at 0xffffffff, row_x1 at 0.
+__global__ void mbrick_extent_kernel(const uint8_t *__restrict__ bricks, int gx, int gy, int gz, uint32_t *__restrict__ row_x0,
+                                     uint32_t *__restrict__ row_x1)
+{
+    const int64_t total = (int64_t)gx * gy * gz;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += (int64_t)gridDim.x * blockDim.x) {
+        const uint8_t *p = bricks + ((size_t)b << 7);
+        uint32_t any = 0;
+        for (int o = 0; o < 125; o++) {
+            any |= (o % 5 != 4) ? (uint32_t)p[o] : 0u;
+        }
+        if (any) {
+            const uint32_t bx = (uint32_t)(b % gx), row = (uint32_t)(b / gx);
+            atomicMin(&row_x0[row], bx);
+            atomicMax(&row_x1[row], bx + 1u);
+        }
+    }
+}
+
+// One thread per 16 bytes of the dense array: bricks inside their row's extent move to their place in the compact array.
+__global__ void mbrick_compact_kernel(const uint4 *__restrict__ dense, int gx, int64_t bricks_total, const uint2 *__restrict__ rows,
+                                      uint4 *__restrict__ compact)
+{
+    const int64_t total = bricks_total * 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i >> 3;
+        const uint32_t bx = (uint32_t)(b % gx), row = (uint32_t)(b / gx);
+        const uint2 ri = rows[row];
+        const uint32_t rel = bx - (ri.y & 0xffffu);
+        if (rel < (ri.y >> 16)) {
+            compact[((size_t)(ri.x + rel) << 3) | (size_t)(i & 7)] = dense[i];
+        }
+    }
+}
+
+// One thread per coarse cell: the minimum clearance (dist - 1, as in build_mbricks_kernel) and the AND of the
+// "interior" flags of the cell's base texels; base texels outside the volume are blocked and not interior.
+__global__ void coarse_clearance_kernel(const uint8_t *__restrict__ dist, int nx, int ny, int nz, int bias, int cshift, int cgx,
+                                        int cgy, int cgz, uint8_t *__restrict__ out)
+{
+    const int64_t total = (int64_t)cgx * cgy * cgz;
+    const int C = 1 << cshift;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % cgx), cy = (int)((i / cgx) % cgy), cz = (int)(i / ((int64_t)cgx * cgy));
+        const int x0 = cx * C - bias, y0 = cy * C - bias, z0 = cz * C - bias;
+        int c = kClearMax;
+        bool interior = true;
+        for (int z = z0; z < z0 + C; z++) {
+            for (int y = y0; y < y0 + C; y++) {
+                for (int x = x0; x < x0 + C; x++) {
+                    const bool in_grid = x >= 0 && y >= 0 && z >= 0 && x < nx && y < ny && z < nz;
+                    const int d = in_grid ? (int)dist[((size_t)z * ny + y) * nx + x] : 0;
+                    c = min(c, d - 1);
+                    interior = interior && x >= 1 && y >= 1 && z >= 1 && x <= nx - 3 && y <= ny - 3 && z <= nz - 3;
+                }
+            }
+        }
+        out[i] = (uint8_t)(max(c, 0) | (interior ? 0x80 : 0));
+    }
+}
+
+hipError_t launch_mbrick_extent(const uint8_t *bricks, int gx, int gy, int gz, uint32_t *row_x0, uint32_t *row_x1, hipStream_t stream)
+{
+    const int64_t total = (int64_t)gx * gy * gz;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 65536 * 4);
+    hipLaunchKernelGGL(mbrick_extent_kernel, dim3(blocks), dim3(256), 0, stream, bricks, gx, gy, gz, row_x0, row_x1);
+    return hipGetLastError();
+}
+
+hipError_t launch_mbrick_compact(const uint8_t *dense, int gx, int gy, int gz, const uint2 *rows, uint8_t *compact, hipStream_t stream)
+{
+    const int64_t total = (int64_t)gx * gy * gz;
+    const int blocks = (int)std::min<int64_t>((total * 8 + 255) / 256, 65536 * 8);
+    hipLaunchKernelGGL(mbrick_compact_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4 *)dense, gx, total, rows, (uint4 *)compact);
+    return hipGetLastError();
+}
+
+hipError_t launch_coarse_clearance(const uint8_t *dist, int nx, int ny, int nz, int bias, int cshift, int cgx, int cgy, int cgz,
+                                   uint8_t *out, hipStream_t stream)
+{
+    const int64_t total = (int64_t)cgx * cgy * cgz;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 65536 * 4);
+    hipLaunchKernelGGL(coarse_clearance_kernel, dim3(blocks), dim3(256), 0, stream, dist, nx, ny, nz, bias, cshift, cgx, cgy, cgz, out);
     return hipGetLastError();
 }
 
@@ -687,6 +776,7 @@ CT_DEV uint32_t lane_rank(uint64_t mask)
 // the march phase's operations, and a sample starts at the state recorded BEFORE the decisive
 // iteration (the one whose fetch is non-zero or leaves the box), which it then executes itself:
 // advance[p] = (position, bits: steps done so far | clearance << 24).
+template <bool SPARSE>
 __global__ __launch_bounds__(256) void primary_advance_kernel(DevScene sc, const float4 *__restrict__ primary,
                                                               float4 *__restrict__ advance)
 {
@@ -716,7 +806,7 @@ __global__ __launch_bounds__(256) void primary_advance_kernel(DevScene sc, const
             pos = add3(pos, stepv);
             steps += 1u;
             uint32_t meta;
-            const uint2 cell = fetch_cell_m(sc, pos, meta);
+            const uint2 cell = fetch_cell_m<SPARSE>(sc, pos, meta);
             dfree = meta & 0x7fu;
             if ((cell.x | cell.y) != 0u || ((meta & 0x80u) == 0u && !in_box(sc, pos))) {
                 break;
@@ -729,7 +819,11 @@ __global__ __launch_bounds__(256) void primary_advance_kernel(DevScene sc, const
 hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream)
 {
     const dim3 grid((sc.width + 31) / 32, (sc.height + 7) / 8), block(256);
-    hipLaunchKernelGGL(primary_advance_kernel, grid, block, 0, stream, sc, primary, advance);
+    if (sc.m_rows) {
+        hipLaunchKernelGGL(primary_advance_kernel<true>, grid, block, 0, stream, sc, primary, advance);
+    } else {
+        hipLaunchKernelGGL(primary_advance_kernel<false>, grid, block, 0, stream, sc, primary, advance);
+    }
     return hipGetLastError();
 }
 
@@ -743,7 +837,7 @@ hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, flo
 // the list of this shard's box-hitting pixels (tile-Morton order).  See BatchArgs for the order.
 // (6 waves per SIMD = 3 blocks of 512 threads per CU: the register allocator must stay within 80 VGPRs.  It
 // uses 75 today; an edit of take_job once moved it to 85 and cost a third of the occupancy, hence the bound.)
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool SPARSE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void render_persistent_kernel(DevScene sc, BatchArgs ba)
 {
     __shared__ MieLdsFull lds;
@@ -1019,7 +1113,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 }
                 pos = add3(pos, stepv);
                 uint32_t meta;
-                const uint2 cell = fetch_cell_m(sc, pos, meta);
+                const uint2 cell = fetch_cell_m<SPARSE>(sc, pos, meta);
                 dfree = meta & 0x7fu;
                 c_dl += 1;
                 work += 1u;
@@ -1889,7 +1983,7 @@ LaunchShape persistent_shape(int device, bool delta)
         // DELTA 768 threads / 64 KiB
         int per_cu = 0;
         const hipError_t e = delta ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_delta_kernel<0, false>, kDeltaThreads, 0)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_persistent_kernel<0, false>, 512, 0);
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_persistent_kernel<0, false, false>, 512, 0);
         if (e != hipSuccess || per_cu < 1) {
             per_cu = delta ? 2 : 3;
         }
@@ -1904,21 +1998,30 @@ LaunchShape persistent_shape(int device, bool delta)
     return s;
 }
 
+template <bool STATS, bool SPARSE>
+static void launch_render_persistent_mode(const DevScene &sc, const BatchArgs &ba, dim3 grid, dim3 block, hipStream_t stream)
+{
+    switch (sc.mode) {
+    case 0: hipLaunchKernelGGL((render_persistent_kernel<0, STATS, SPARSE>), grid, block, 0, stream, sc, ba); break;
+    case 1: hipLaunchKernelGGL((render_persistent_kernel<1, STATS, SPARSE>), grid, block, 0, stream, sc, ba); break;
+    default: hipLaunchKernelGGL((render_persistent_kernel<2, STATS, SPARSE>), grid, block, 0, stream, sc, ba); break;
+    }
+}
+
 hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream)
 {
     const dim3 grid(shape.blocks), block(shape.threads);
+    const bool sparse = sc.m_rows != nullptr;
     if (shape.stats) { // diagnostics build of the same kernel
-        switch (sc.mode) {
-        case 0: hipLaunchKernelGGL((render_persistent_kernel<0, true>), grid, block, 0, stream, sc, ba); break;
-        case 1: hipLaunchKernelGGL((render_persistent_kernel<1, true>), grid, block, 0, stream, sc, ba); break;
-        default: hipLaunchKernelGGL((render_persistent_kernel<2, true>), grid, block, 0, stream, sc, ba); break;
+        if (sparse) {
+            launch_render_persistent_mode<true, true>(sc, ba, grid, block, stream);
+        } else {
+            launch_render_persistent_mode<true, false>(sc, ba, grid, block, stream);
         }
+    } else if (sparse) {
+        launch_render_persistent_mode<false, true>(sc, ba, grid, block, stream);
     } else {
-        switch (sc.mode) {
-        case 0: hipLaunchKernelGGL((render_persistent_kernel<0, false>), grid, block, 0, stream, sc, ba); break;
-        case 1: hipLaunchKernelGGL((render_persistent_kernel<1, false>), grid, block, 0, stream, sc, ba); break;
-        default: hipLaunchKernelGGL((render_persistent_kernel<2, false>), grid, block, 0, stream, sc, ba); break;
-        }
+        launch_render_persistent_mode<false, false>(sc, ba, grid, block, stream);
     }
     return hipGetLastError();
 }

@@ -67,8 +67,8 @@ namespace DeepestScatter
         // Resources::loadVolumeBuffer (Resources.cpp:68-155): returns the uint8 texture (zero border
         // included) and its size in texels.  Sources: "procedural:<N>[:<seed>]" (the synthetic
         // benchmark cloud) or a raw float grid "<file>.f32grid" = int32 nx,ny,nz + nx*ny*nz floats
-        // (x fastest), which goes through the reference's quantiser.  .vdb needs OpenVDB, which is
-        // not available on the target image.
+        // (x fastest), which goes through the reference's quantiser, or a .vdb file -- the reference's own
+        // input -- read by host/VdbReader.h (no OpenVDB needed).
         std::tuple<std::vector<uint8_t>, std::array<uint32_t, 3>> loadVolumeBuffer(const std::string& path, bool createMipmaps)
         {
             std::cout << "Loading volume... " << path << std::endl;
@@ -94,7 +94,19 @@ namespace DeepestScatter
                 if (ct_quantize_volume(grid.data(), pd, tex.data()) != CT_OK) throw std::runtime_error("ct_quantize_volume failed");
                 return { std::move(tex), { pd[0] + 2, pd[1] + 2, pd[2] + 2 } };
             }
-            throw std::runtime_error("unsupported volume '" + path + "' (.vdb needs OpenVDB; use procedural:<N> or .f32grid)");
+            if (path.size() > 4 && path.substr(path.size() - 4) == ".vdb")
+            {
+                // the reference's own input (Resources.cpp:82-143), read without OpenVDB: ct_load_vdb -> host/VdbReader.h
+                uint32_t d[3] = { 0, 0, 0 };
+                size_t bytes = 0;
+                char err[512] = { 0 };
+                if (ct_load_vdb(path.c_str(), d, nullptr, 0, &bytes, err, sizeof err) != CT_OK) throw std::runtime_error(path + ": " + err);
+                std::vector<uint8_t> tex(bytes);
+                if (ct_load_vdb(path.c_str(), d, tex.data(), tex.size(), &bytes, err, sizeof err) != CT_OK) throw std::runtime_error(path + ": " + err);
+                std::cout << "Creating buffer of size " << d[0] << "x" << d[1] << "x" << d[2] << std::endl;   // Resources.cpp:119
+                return { std::move(tex), { d[0], d[1], d[2] } };
+            }
+            throw std::runtime_error("unsupported volume '" + path + "' (use <file>.vdb, procedural:<N> or <file>.f32grid)");
         }
 
         // The Lorenz-Mie tables (data of Mie.cpp:8-8203) shipped as deepestscatter_amd/data/mie_raw.f32.

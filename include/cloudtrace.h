@@ -331,6 +331,12 @@ CT_API int ct_debug_suspended(CtHandle h, uint64_t *paths_out);
  * (0 unless out[0]). */
 CT_API int ct_debug_invariants(CtHandle h, uint64_t out[8]);
 
+/* Device memory of the volume representations (bytes): out[0] raw density texture, out[1] density apron bricks,
+ * out[2] shadow-volume apron bricks, out[3] march bricks if stored densely, out[4] march bricks as stored,
+ * out[5] = 1 when they are stored sparsely (row extents; volumes >= 768^3 texels or CT_SPARSE=1), out[6] bytes of the
+ * row-extent table, out[7] bytes of the coarse clearance grid. */
+CT_API int ct_debug_memory(CtHandle h, uint64_t out[8]);
+
 /* PMC calibration probe (no handle): allocates 2^log2_lines 128-byte lines on `device`, and has one
  * thread per line issue the estimator's access pattern (two unaligned 8-byte loads at byte 13 and
  * byte 38 of a pseudo-randomly chosen, never repeated line).  Under rocprofv3 --pmc FETCH_SIZE this
@@ -354,6 +360,15 @@ CT_API int ct_calculate_camera_variables(const float eye[3], const float lookat[
  * (nx*ny*nz, x fastest) -> uint8 texture of (nx+2)(ny+2)(nz+2) with a 1-texel zero border,
  * value = (uint8)(v / max * 255) computed in double, truncating. */
 CT_API int ct_quantize_volume(const float *grid_host, const uint32_t payload_dims[3], uint8_t *texture_host_out);
+
+/* Resources::loadVolumeBuffer for a .vdb file, Resources.cpp:82-143, without OpenVDB (deepestscatter_amd/host/
+ * VdbReader.h reads the file format): the FIRST grid of the file, which must be a FloatGrid; maxDensity = the largest
+ * ACTIVE value; the active bounding box expanded by one voxel on every side; dense fill by getValue (inactive voxels
+ * and tiles included), x fastest; uint8 = (uint8)(value / maxDensity * 255).  dims_out = the texture's size in
+ * texels (what CtScene::dims wants); texture_host_out may be NULL to query dims_out / *bytes_out.  On failure the
+ * message (unsupported compression codec, not a FloatGrid, ...) goes to error_out. */
+CT_API int ct_load_vdb(const char *path, uint32_t dims_out[3], uint8_t *texture_host_out, size_t capacity, size_t *bytes_out,
+                       char *error_out, size_t error_capacity);
 
 /* Resources::generateMipmaps, Resources.cpp:169-209: level count = floor(log2(maxdim))+1; each
  * level is the 2x2x2 integer mean (uint16 sum / 8, zero outside).  level_offsets_out[l] = byte

@@ -10,11 +10,11 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libcloudtrace.so"
 
 CT_ABI_VERSION = 1
-CT_OK, CT_E_INVAL, CT_E_HIP, CT_E_NOMEM, CT_E_STATE, CT_E_NODEVICE = 0, -1, -2, -3, -4, -5
+CT_OK, CT_E_INVAL, CT_E_HIP, CT_E_NOMEM, CT_E_STATE, CT_E_NODEVICE, CT_E_RCCL = 0, -1, -2, -3, -4, -5, -6
 CT_MODE_SUN_AND_SKY_ALL_SCATTER, CT_MODE_SUN_MULTIPLE_SCATTER, CT_MODE_SUN_SINGLE_SCATTER = 0, 1, 2
 CT_EST_MARCH, CT_EST_DELTA = 0, 1
 CT_BUF_MEAN, CT_BUF_M2, CT_BUF_FRAME, CT_BUF_SCREEN, CT_BUF_INSCATTER, CT_BUF_DENSITY = range(6)
-CT_FLAG_NONE, CT_FLAG_SIMPLE_KERNEL, CT_FLAG_LIGHT_NORMALIZED = 0, 1, 2
+CT_FLAG_NONE, CT_FLAG_SIMPLE_KERNEL, CT_FLAG_LIGHT_NORMALIZED, CT_FLAG_SPARSE_BRICKS = 0, 1, 2, 4
 
 # every symbol include/cloudtrace.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -23,6 +23,9 @@ EXPORTS = [
     "ct_buffer_bytes", "ct_copy_to_device", "ct_device_ptr", "ct_subframes", "ct_set_subframes", "ct_counters", "ct_kernel_time",
     "ct_debug_cdf_inversion", "ct_debug_fetch_probe", "ct_debug_stats", "ct_debug_suspended", "ct_debug_invariants", "ct_debug_memory", "ct_fetch_counters", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_load_vdb", "ct_generate_mipmaps",
     "ct_tile_owner", "ct_make_procedural_cloud",
+    "ct_group_create", "ct_group_destroy", "ct_group_last_error", "ct_group_size", "ct_group_handle", "ct_group_set_camera",
+    "ct_group_render_accumulate", "ct_group_reset", "ct_group_merge", "ct_group_download", "ct_group_tonemap",
+    "ct_group_is_converged", "ct_group_counters",
 ]
 
 
@@ -134,6 +137,19 @@ def load():
         "ct_load_vdb": (i32, [C.c_char_p, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
         "ct_generate_mipmaps": (i32, [vp, vp, vp, C.c_size_t, C.POINTER(u32), C.POINTER(C.c_size_t), vp]),
         "ct_tile_owner": (u32, [u32, u32, u32]),
+        "ct_group_create": (i32, [C.POINTER(CtScene), vp, u32, C.POINTER(vp)]),
+        "ct_group_destroy": (i32, [vp]),
+        "ct_group_last_error": (C.c_char_p, [vp]),
+        "ct_group_size": (i32, [vp, C.POINTER(u32)]),
+        "ct_group_handle": (i32, [vp, u32, C.POINTER(vp)]),
+        "ct_group_set_camera": (i32, [vp, vp, vp, vp, vp]),
+        "ct_group_render_accumulate": (i32, [vp, u32, u32]),
+        "ct_group_reset": (i32, [vp]),
+        "ct_group_merge": (i32, [vp]),
+        "ct_group_download": (i32, [vp, i32, vp, C.c_size_t]),
+        "ct_group_tonemap": (i32, [vp, f32, vp, C.POINTER(f32)]),
+        "ct_group_is_converged": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_uint64)]),
+        "ct_group_counters": (i32, [vp, C.POINTER(CtCounters)]),
         "ct_make_procedural_cloud": (i32, [u32, u32, vp]),
     }
     for name, (res, args) in sig.items():

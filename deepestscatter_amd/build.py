@@ -18,7 +18,7 @@ CSRC = PKG / "csrc"
 ROOT = PKG.parent
 LIB = PKG / "libcloudtrace.so"
 
-SOURCES = ["ct_kernels.hip", "ct_api.cpp", "ct_host.cpp"]
+SOURCES = ["ct_kernels.hip", "ct_group.hip", "ct_api.cpp", "ct_host.cpp"]
 HEADERS = [CSRC / "ct_device.hpp", CSRC / "ct_internal.hpp", ROOT / "include" / "cloudtrace.h",
            ROOT / "include" / "ct_fmath.h", PKG / "host" / "VdbReader.h"]
 
@@ -64,7 +64,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> Path:
 def build(force: bool = False, verbose: bool = False) -> Path:
     if force or needs_build():
         # CT_EXTRA_FLAGS: e.g. -DCT_DEBUG_BOUNDS (device-side index checks that report instead of faulting)
-        cmd = [hipcc(), *FLAGS, *os.environ.get("CT_EXTRA_FLAGS", "").split(), "-o", str(LIB), *[str(CSRC / s) for s in SOURCES], "-lz"]
+        cmd = [hipcc(), *FLAGS, *os.environ.get("CT_EXTRA_FLAGS", "").split(), "-o", str(LIB), *[str(CSRC / s) for s in SOURCES], "-lz", "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=str(CSRC))

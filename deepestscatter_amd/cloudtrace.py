@@ -146,42 +146,48 @@ class SceneParams:
     flags: int = 0
 
 
+def make_scene(density: np.ndarray, p: SceneParams):
+    """-> (CtScene, objects that must stay alive until ct_create / ct_group_create has copied the host data)."""
+    density = np.ascontiguousarray(density, np.uint8)
+    if density.ndim != 3:
+        raise ValueError("density must be uint8 [Z, Y, X]")
+    mie, chopped = load_mie_raw()
+    s = CtScene()
+    s.abi_version = _lib.CT_ABI_VERSION
+    nz, ny, nx = density.shape
+    s.dims[:] = (nx, ny, nz)
+    s.density_host = density.ctypes.data
+    s.cloud_size_m = p.cloud_size_m
+    s.mean_free_path_m = p.mean_free_path_m
+    s.sample_step = p.sample_step
+    s.mode = p.mode
+    s.estimator = p.estimator
+    s.max_depth = p.max_depth
+    s.light_direction[:] = p.light_direction
+    s.light_color[:] = p.light_color
+    s.light_intensity = p.light_intensity
+    s.width, s.height = p.width, p.height
+    s.mie_host = mie.ctypes.data
+    s.chopped_mie_host = chopped.ctypes.data
+    s.mie_count = 4096
+    s.device = p.device
+    s.shard_index, s.shard_count = p.shard_index, p.shard_count
+    s.flags = p.flags
+    return s, (density, mie, chopped)
+
+
 class CloudTracer:
     """Owns one CtHandle.  `density` is the uint8 [Z,Y,X] texture incl. its zero border."""
 
     def __init__(self, density: np.ndarray, params: SceneParams | None = None, **kw):
         self.L = _lib.load()
         self.params = params or SceneParams(**kw)
-        p = self.params
-        density = np.ascontiguousarray(density, np.uint8)
-        if density.ndim != 3:
-            raise ValueError("density must be uint8 [Z, Y, X]")
-        mie, chopped = load_mie_raw()
-        s = CtScene()
-        s.abi_version = _lib.CT_ABI_VERSION
-        nz, ny, nx = density.shape
-        s.dims[:] = (nx, ny, nz)
-        s.density_host = density.ctypes.data
-        s.cloud_size_m = p.cloud_size_m
-        s.mean_free_path_m = p.mean_free_path_m
-        s.sample_step = p.sample_step
-        s.mode = p.mode
-        s.estimator = p.estimator
-        s.max_depth = p.max_depth
-        s.light_direction[:] = p.light_direction
-        s.light_color[:] = p.light_color
-        s.light_intensity = p.light_intensity
-        s.width, s.height = p.width, p.height
-        s.mie_host = mie.ctypes.data
-        s.chopped_mie_host = chopped.ctypes.data
-        s.mie_count = 4096
-        s.device = p.device
-        s.shard_index, s.shard_count = p.shard_index, p.shard_count
-        s.flags = p.flags
-        self.dims = (nx, ny, nz)
-        self.width, self.height = p.width, p.height
+        s, keep = make_scene(density, self.params)
+        self.dims = tuple(int(v) for v in s.dims)
+        self.width, self.height = self.params.width, self.params.height
         h = C.c_void_p()
         rc = self.L.ct_create(C.byref(s), C.byref(h))
+        del keep
         check(rc, None)
         self.h = h
 
@@ -386,6 +392,81 @@ class CloudTracer:
         out = np.empty(count, np.uint32)
         check(self.L.ct_debug_cdf_inversion(self.h, first_u24, count, _p(out)), self.h)
         return out
+
+
+class TracerGroup:
+    """Owns one CtGroup: a multi-GPU job driven by ONE process below the C ABI (ct_group_*; RCCL frame reduce).
+    `devices` may repeat a device to rehearse an N-GPU job on fewer GPUs (merged without a collective then)."""
+
+    def __init__(self, density: np.ndarray, devices, params: SceneParams | None = None, **kw):
+        self.L = _lib.load()
+        self.params = params or SceneParams(**kw)
+        s, keep = make_scene(density, self.params)
+        self.width, self.height = self.params.width, self.params.height
+        dev = np.asarray(list(devices), np.int32)
+        g = C.c_void_p()
+        rc = self.L.ct_group_create(C.byref(s), _p(dev), len(dev), C.byref(g))
+        del keep
+        if rc != _lib.CT_OK:
+            msg = self.L.ct_group_last_error(None)
+            raise _lib.CloudTraceError(rc, msg.decode("utf-8", "replace") if msg else "")
+        self.g = g
+
+    def _check(self, rc):
+        if rc != _lib.CT_OK:
+            msg = self.L.ct_group_last_error(self.g)
+            raise _lib.CloudTraceError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.ct_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_camera(self, eye, U, V, W):
+        a = [np.asarray(v, np.float32) for v in (eye, U, V, W)]
+        self._check(self.L.ct_group_set_camera(self.g, *[_p(v) for v in a]))
+
+    def render_accumulate(self, first_subframe_id: int, count: int):
+        self._check(self.L.ct_group_render_accumulate(self.g, first_subframe_id, count))
+
+    def reset(self):
+        self._check(self.L.ct_group_reset(self.g))
+
+    def merge(self):
+        self._check(self.L.ct_group_merge(self.g))
+
+    def _download(self, which):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self.L.ct_group_download(self.g, which, _p(out), out.nbytes))
+        return out
+
+    def mean(self):
+        return self._download(CT_BUF_MEAN)
+
+    def m2(self):
+        return self._download(CT_BUF_M2)
+
+    def tonemap(self, exposure: float = 0.4):
+        screen = np.empty((self.height, self.width, 4), np.uint8)
+        avg = C.c_float(0)
+        self._check(self.L.ct_group_tonemap(self.g, exposure, _p(screen), C.byref(avg)))
+        return screen, float(avg.value)
+
+    def is_converged(self):
+        ok, bad = C.c_int32(0), C.c_uint64(0)
+        self._check(self.L.ct_group_is_converged(self.g, C.byref(ok), C.byref(bad)))
+        return bool(ok.value), int(bad.value)
+
+    def counters(self) -> dict:
+        c = CtCounters()
+        self._check(self.L.ct_group_counters(self.g, C.byref(c)))
+        return c.as_dict()
 
 
 def algorithmic_bytes(counters: dict, pixels_times_spp: int) -> int:

@@ -556,9 +556,14 @@ static int create_impl(const CtScene *s, CtHandle h)
         const hipError_t e = launch_build_mbricks(h->d_density, nx, ny, nz, mbias, bbias, (int)mgx, (int)bgy, (int)bgz,
                                                   tmp_a, tmp_b, h->d_mbricks, h->stream);
         const hipError_t e2 = hipStreamSynchronize(h->stream);
-        // Sparse storage (BASELINE.json configs[4]: "1024^3 sparse brick-compressed density"): for volumes of 768^3
-        // texels and more, where the dense array (2.9 GB at 1024^3) is far beyond every cache; CT_SPARSE=0/1 overrides.
-        bool sparse = (uint64_t)nx * ny * nz >= 768ull * 768ull * 768ull;
+        // Sparse storage (BASELINE.json configs[4]: "1024^3 sparse brick-compressed density"): CT_FLAG_SPARSE_BRICKS, or
+        // CT_SPARSE=0/1 in the environment.  Not the default at any size: measured at 1024^3 / 2048^2 the stored bricks
+        // shrink from 3.41 GB to 0.36 GB, but the march runs 20 % slower (1670 vs 2083 Msamples/s,
+        // profiles/r02c/ab_sparse_1024.log) -- the row-extent lookup is one more dependent load in a gather that is bound
+        // by latency and by the L1's address rate, and only 5 % of the fetches land outside the stored extents, so there
+        // are few line fills to save.  With 288 GB of HBM the dense array is the faster choice; this is the option for
+        // when capacity matters.
+        bool sparse = (s->flags & CT_FLAG_SPARSE_BRICKS) != 0;
         if (const char *env = getenv("CT_SPARSE")) {
             sparse = atoi(env) != 0;
         }

@@ -79,7 +79,7 @@ struct DevScene {
     // bit 7 = "interior" for the row's bases (1 <= base <= N-3 on every axis: isInBox holds for
     // every position based there and for a scatter position backed off from it).
     const uint8_t *mbricks;
-    // Sparse march bricks (volumes of 768^3 texels and more, CT_SPARSE): of every brick row (by, bz) only the bricks
+    // Sparse march bricks (CT_FLAG_SPARSE_BRICKS / CT_SPARSE=1): of every brick row (by, bz) only the bricks
     // between its first and its last one that holds a non-zero texel are stored, one row after the other.
     // m_rows[bz * brick_gy + by] = (line index of the row's first stored brick, x0 | count << 16).  A footprint based
     // in a brick outside its row's extent is all zero by construction; its clearance and "interior" flag come

@@ -46,18 +46,17 @@ namespace DeepestScatter
             s.chopped_mie_host = context->choppedMie.data();
             s.mie_count = (uint32_t)context->mie.size();
             s.estimator = estimator;
-            context->destroy();
-            Context::check(ct_create(&s, &context->handle), nullptr, "ct_create");
+            context->create();
             context->density.clear();
             context->density.shrink_to_fit();
         }
 
         void render(float* frameResultBuffer) override                           // PathTracingRenderer.cpp:21-31
         {
+            if (context->group) throw std::runtime_error("the two-launch loop (--unfused) renders on one GPU only");
             if (camera.valid)
             {
-                Context::check(ct_set_camera(context->handle, camera.eye.data(), camera.U.data(), camera.V.data(), camera.W.data()),
-                               context->handle, "ct_set_camera");
+                context->setCamera(camera.eye.data(), camera.U.data(), camera.V.data(), camera.W.data());
                 camera.valid = false;
             }
             Context::check(ct_render_subframe(context->handle, subframeId, frameResultBuffer), context->handle, "ct_render_subframe");
@@ -106,7 +105,7 @@ namespace DeepestScatter
         void reset() override                                                    // :77-86
         {
             subframeId = 0;
-            Context::check(ct_reset(context->handle), context->handle, "ct_reset");
+            context->resetAccumulation();
         }
 
         bool isCompleted() override { return completed; }
@@ -129,7 +128,7 @@ namespace DeepestScatter
         void saveToDisk() const                                                  // :149-175
         {
             std::vector<float> mean((size_t)width * height * 4);
-            Context::check(ct_download(context->handle, CT_BUF_MEAN, mean.data(), mean.size() * sizeof(float)), context->handle, "ct_download");
+            context->downloadMean(mean.data(), mean.size() * sizeof(float));
             std::cout << mean[((size_t)width * height / 2 + width / 2) * 4] << std::endl;   // :163
             if (outputFile.extension() == ".pfm")
             {
@@ -178,14 +177,10 @@ namespace DeepestScatter
                     CameraProgram* camera = renderer->getCamera();
                     if (camera->valid)
                     {
-                        Context::check(ct_set_camera(context->handle, camera->eye.data(), camera->U.data(), camera->V.data(), camera->W.data()),
-                                       context->handle, "ct_set_camera");
+                        context->setCamera(camera->eye.data(), camera->U.data(), camera->V.data(), camera->W.data());
                         camera->valid = false;
                     }
-                    if (headless)
-                        Context::check(ct_render_accumulate_async(context->handle, subframeId + 1, count), context->handle, "ct_render_accumulate_async");
-                    else
-                        Context::check(ct_render_accumulate(context->handle, subframeId + 1, count), context->handle, "ct_render_accumulate");
+                    context->renderAccumulate(subframeId + 1, count, headless);
                     subframeId += count;
                     std::cout << "rendering subframe " << subframeId << std::endl;
                 }
@@ -203,7 +198,7 @@ namespace DeepestScatter
                 if (!headless || subframeId % 40 == 0)
                 {
                     screen.resize((size_t)width * height * 4);
-                    Context::check(ct_tonemap(context->handle, exposure, screen.data(), nullptr), context->handle, "ct_tonemap");   // :202-210
+                    context->tonemap(exposure, screen.data());                    // :202-210
                 }
                 if (subframeId % 40 == 0) saveToDisk();                           // :211-214
             }
@@ -218,11 +213,10 @@ namespace DeepestScatter
         bool isConverged()                                                       // :232-268 (evaluated on the device)
         {
             if (subframeId < 100) return false;
-            int32_t converged = 0;
             uint64_t left = 0;
-            Context::check(ct_is_converged(context->handle, &converged, &left), context->handle, "ct_is_converged");
+            const bool converged = context->isConverged(left);
             std::cout << "Converged: " << (uint64_t)width * height - left << "/" << (uint64_t)width * height << " --- " << left << "left" << std::endl;
-            return converged != 0;
+            return converged;
         }
 
         uint32_t width, height;

@@ -33,7 +33,11 @@ namespace DeepestScatter
         Context(const Context&) = delete;
         Context& operator=(const Context&) = delete;
 
-        void destroy() { if (handle) { ct_destroy(handle); handle = nullptr; } }   // GuiExecutionLoop.cpp:93-97
+        void destroy()                                                               // GuiExecutionLoop.cpp:93-97
+        {
+            if (group) { ct_group_destroy(group); group = nullptr; }
+            if (handle) { ct_destroy(handle); handle = nullptr; }
+        }
 
         static void check(int rc, CtHandle h, const char* what)
         {
@@ -43,8 +47,57 @@ namespace DeepestScatter
             }
         }
 
+        static void checkGroup(int rc, CtGroup g, const char* what)
+        {
+            if (rc != CT_OK) throw std::runtime_error(std::string(what) + ": " + ct_group_last_error(g));
+        }
+
+        // One renderer handle, or (devices.size() > 1: cloudtrace --gpus) a group of them, one per GPU, each rendering
+        // its pixel tiles; the calls Camera makes go to whichever exists (the group merges the shards with RCCL).
+        void create()
+        {
+            destroy();
+            if (devices.size() > 1) checkGroup(ct_group_create(&scene, devices.data(), (uint32_t)devices.size(), &group), nullptr, "ct_group_create");
+            else { if (!devices.empty()) scene.device = devices[0]; check(ct_create(&scene, &handle), nullptr, "ct_create"); }
+        }
+        void setCamera(const float* eye, const float* U, const float* V, const float* W)
+        {
+            if (group) checkGroup(ct_group_set_camera(group, eye, U, V, W), group, "ct_group_set_camera");
+            else check(ct_set_camera(handle, eye, U, V, W), handle, "ct_set_camera");
+        }
+        void renderAccumulate(uint32_t first, uint32_t count, bool enqueue)
+        {
+            if (group) checkGroup(ct_group_render_accumulate(group, first, count), group, "ct_group_render_accumulate");
+            else if (enqueue) check(ct_render_accumulate_async(handle, first, count), handle, "ct_render_accumulate_async");
+            else check(ct_render_accumulate(handle, first, count), handle, "ct_render_accumulate");
+        }
+        void resetAccumulation()
+        {
+            if (group) checkGroup(ct_group_reset(group), group, "ct_group_reset");
+            else check(ct_reset(handle), handle, "ct_reset");
+        }
+        void downloadMean(float* dst, size_t bytes)
+        {
+            if (group) checkGroup(ct_group_download(group, CT_BUF_MEAN, dst, bytes), group, "ct_group_download");
+            else check(ct_download(handle, CT_BUF_MEAN, dst, bytes), handle, "ct_download");
+        }
+        void tonemap(float exposure, uint8_t* screen)
+        {
+            if (group) checkGroup(ct_group_tonemap(group, exposure, screen, nullptr), group, "ct_group_tonemap");
+            else check(ct_tonemap(handle, exposure, screen, nullptr), handle, "ct_tonemap");
+        }
+        bool isConverged(uint64_t& left)
+        {
+            int32_t converged = 0;
+            if (group) checkGroup(ct_group_is_converged(group, &converged, &left), group, "ct_group_is_converged");
+            else check(ct_is_converged(handle, &converged, &left), handle, "ct_is_converged");
+            return converged != 0;
+        }
+
         CtScene scene{};
         CtHandle handle = nullptr;
+        CtGroup group = nullptr;
+        std::vector<int32_t> devices;       // empty: device 0
         std::vector<uint8_t> density;       // filled by VDBCloud::InitVolume
         std::vector<float> mie, choppedMie; // filled by Scene::init (Mie::get*Sampler)
     };

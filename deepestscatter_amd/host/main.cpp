@@ -5,6 +5,7 @@
 //
 //   cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light Side|Back|Front]
 //              [--size-m 7000] [--out DIR] [--data DIR] [--unfused] [--display] [--estimator march|delta] [--format exr|pfm]
+//              [--gpus N | --gpus a,b,c]   one process, one shard of 8x8-pixel tiles per GPU, RCCL reduce of [mean | M2] (ct_group_*)
 //   <cloud> = procedural:<N>[:<seed>] | file.f32grid
 #include <chrono>
 #include <cstring>
@@ -47,6 +48,7 @@ namespace
         bool fused = true;
         bool display = false;                                                     // --display: tonemap + convergence test after every update, like the GUI
         int estimator = CT_EST_MARCH;                                             // --estimator delta: Woodcock tracking (not the reference's sampler)
+        std::vector<int32_t> devices;                                             // --gpus N | --gpus a,b,c: pixel-tile shards, RCCL frame reduce (ct_group_*)
     };
 
     using LazyTask = std::function<std::shared_ptr<Scene>()>;
@@ -56,6 +58,7 @@ namespace
         return [=]()
         {
             auto context = std::make_shared<Context>();
+            context->devices = opt.devices;
             auto resources = std::make_shared<Resources>(context);
             // installSceneSetup (installers.cpp:65-105)
             const float3 direction = normalize(getLightDirection(lightDirection));
@@ -88,7 +91,7 @@ int main(int argc, char* argv[])
     try
     {
         Options opt;
-        if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused] [--display] [--estimator march|delta] [--format exr|pfm]\n"; return 2; }
+        if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused] [--display] [--estimator march|delta] [--format exr|pfm] [--gpus N|a,b,c]\n"; return 2; }
         opt.cloud = argv[1];
         opt.dataDir = (std::filesystem::path(argv[0]).parent_path() / ".." / "data").string();
         for (int i = 2; i < argc; i++)
@@ -101,6 +104,15 @@ int main(int argc, char* argv[])
             else if (a == "--out") opt.outDir = next();
             else if (a == "--data") opt.dataDir = next();
             else if (a == "--unfused") opt.fused = false;
+            else if (a == "--gpus")
+            {
+                // "N" = devices 0..N-1; "a,b,c" = that list (a device may repeat: a rehearsal of N shards on fewer GPUs)
+                const std::string v = next();
+                opt.devices.clear();
+                if (v.find(',') == std::string::npos) { for (int d = 0; d < std::stoi(v); d++) opt.devices.push_back(d); }
+                else { size_t p = 0; while (p <= v.size()) { const size_t q = v.find(',', p); opt.devices.push_back(std::stoi(v.substr(p, q - p))); if (q == std::string::npos) break; p = q + 1; } }
+                if (opt.devices.empty()) throw std::invalid_argument("--gpus N | --gpus a,b,c");
+            }
             else if (a == "--display") opt.display = true;
             else if (a == "--estimator")
             {

@@ -50,7 +50,8 @@ typedef enum CtStatus {
     CT_E_HIP = -2,     /* a HIP call or kernel failed (optix::Exception path, main.cpp:65-69) */
     CT_E_NOMEM = -3,   /* host or device allocation failed */
     CT_E_STATE = -4,   /* call order violated (e.g. render before ct_set_camera) */
-    CT_E_NODEVICE = -5 /* no usable gfx950 device / extension missing */
+    CT_E_NODEVICE = -5, /* no usable gfx950 device / extension missing */
+    CT_E_RCCL = -6     /* librccl missing or a collective failed (ct_group_*) */
 } CtStatus;
 
 /* Cloud::Rendering::Mode, src/Scene/SceneDescription.h:39-44 -> program chosen in
@@ -125,6 +126,10 @@ typedef struct CtScene {
 #define CT_FLAG_LIGHT_NORMALIZED 2u /* light_direction already went through the reference's two
                                        normalisations (a host that mirrors installSceneSetup +
                                        DirectionalLight); use it as is */
+
+#define CT_FLAG_SPARSE_BRICKS 4u    /* store the MARCH estimator's density bricks sparsely (only the bricks between the first and
+                                       the last non-empty one of every brick row; 9.5x smaller at 1024^3, 20 % slower: for
+                                       volumes whose dense bricks would not fit; identical results) */
 
 /* Deterministic work counters of everything rendered since create/ct_reset
  * (the algorithmic-bytes figure is built from these). */
@@ -333,7 +338,7 @@ CT_API int ct_debug_invariants(CtHandle h, uint64_t out[8]);
 
 /* Device memory of the volume representations (bytes): out[0] raw density texture, out[1] density apron bricks,
  * out[2] shadow-volume apron bricks, out[3] march bricks if stored densely, out[4] march bricks as stored,
- * out[5] = 1 when they are stored sparsely (row extents; volumes >= 768^3 texels or CT_SPARSE=1), out[6] bytes of the
+ * out[5] = 1 when they are stored sparsely (row extents; CT_FLAG_SPARSE_BRICKS or CT_SPARSE=1), out[6] bytes of the
  * row-extent table, out[7] bytes of the coarse clearance grid. */
 CT_API int ct_debug_memory(CtHandle h, uint64_t out[8]);
 
@@ -347,6 +352,35 @@ CT_API int ct_debug_fetch_probe(int32_t device, uint32_t log2_lines, uint32_t re
 /* Self-test hook: k(val) of the CDF inversion (cloud.cuh:162-180) for `count` consecutive 24-bit
  * random integers starting at first_u24, evaluated by the device code; cos(theta) = (2k+1)/65536-1. */
 CT_API int ct_debug_cdf_inversion(CtHandle h, uint32_t first_u24, uint32_t count, uint32_t *k_host_out);
+
+/* ---- multi-GPU below the C ABI: one process, the GPUs of one node (SURVEY section 8b "multi-GPU is internal",
+ * section 8e) ------------------------------------------------------------------------------------------------------
+ * The reference is single-GPU; BASELINE.json shards the frame by pixel tile over the GPUs of a
+ * node and reduces the accumulated radiance buffer with RCCL.  A CtGroup is that for a C or C++ host: one CtHandle
+ * per entry of `devices` (handle i renders the tiles of shard i of `count`, see ct_tile_owner) and an RCCL
+ * communicator over them (ncclCommInitAll; librccl is loaded on first use, CT_E_RCCL when it cannot be).
+ * ct_group_render_accumulate enqueues the batch on every device and waits for all of them; ct_group_merge SUM-reduces
+ * every shard's [mean | M2] (2 x W*H float4; foreign pixels are exactly 0, so the sum is the merged frame, bit for bit
+ * the single-GPU image) onto devices[0] with one ncclReduce per device inside ncclGroupStart/End; ct_group_download,
+ * ct_group_tonemap and ct_group_is_converged work on the merged frame (and merge first when needed).
+ * scene->device, shard_index and shard_count are ignored.  A device may appear more than once in `devices` -- a
+ * rehearsal of an N-GPU job on fewer GPUs; RCCL refuses two ranks on one device, so such a group merges with peer
+ * copies and an add kernel instead of a collective.  The Python host does the same job with one process per GPU over
+ * torch.distributed (deepestscatter_amd/distributed.py); both produce identical frames. */
+typedef struct CtGroup_ *CtGroup;
+CT_API int ct_group_create(const CtScene *scene, const int32_t *devices, uint32_t count, CtGroup *out);
+CT_API int ct_group_destroy(CtGroup g);
+CT_API const char *ct_group_last_error(CtGroup g);      /* g == NULL: last failure of ct_group_create in this thread */
+CT_API int ct_group_size(CtGroup g, uint32_t *count_out);
+CT_API int ct_group_handle(CtGroup g, uint32_t index, CtHandle *out);   /* shard `index` (owned by the group) */
+CT_API int ct_group_set_camera(CtGroup g, const float eye[3], const float U[3], const float V[3], const float W[3]);
+CT_API int ct_group_render_accumulate(CtGroup g, uint32_t first_subframe_id, uint32_t count);
+CT_API int ct_group_reset(CtGroup g);
+CT_API int ct_group_merge(CtGroup g);
+CT_API int ct_group_download(CtGroup g, int32_t which /*CT_BUF_MEAN | CT_BUF_M2*/, void *dst_host, size_t dst_bytes);
+CT_API int ct_group_tonemap(CtGroup g, float exposure, uint8_t *rgba_host, float *avg_luminance_out);
+CT_API int ct_group_is_converged(CtGroup g, int32_t *converged_out, uint64_t *unconverged_pixels_out);
+CT_API int ct_group_counters(CtGroup g, CtCounters *out);              /* sums over the shards */
 
 /* ---- host-side helpers of the same path (pure CPU, no handle, no GPU) ------------------- */
 

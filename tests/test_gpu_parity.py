@@ -1087,3 +1087,49 @@ def test_sparse_march_bricks_are_bit_exact_and_smaller(monkeypatch):
     # fewer line fetches are issued for the same lookups?  not necessarily fewer -- but never a different algorithm count
     a.close()
     b.close()
+
+
+def test_group_api_merges_shards_below_the_c_abi(tmp_path):
+    """ct_group_*: one process, one handle per entry of the device list, frame reduce of [mean | M2] onto the first
+    device.  With one GPU on the box: (a) a group of one device goes through a real RCCL communicator (ncclCommInitAll
+    + ncclReduce of one rank); (b) a device list that repeats device 0 three times rehearses three shards -- RCCL
+    refuses two ranks on one device, so that group merges with copies and an add kernel.  Merged mean, M2, counters,
+    tonemapped screen, average luminance and the convergence count must equal the single handle's; so must the C++
+    host's picture with --gpus 0,0."""
+    tex = sphere_volume(40, radius=0.42, seed=33)
+    w, h, spp = 88, 64, 110
+    kw = dict(mode=0, cloud_size_m=3000.0, max_depth=200)
+    one = ds.CloudTracer(tex, width=w, height=h, **kw)
+    one.render_accumulate(1, 60)
+    one.render_accumulate(61, spp - 60)
+    want = (one.mean(), one.m2(), one.counters(), one.tonemap(0.4), one.is_converged())
+    one.close()
+    for devices in ([0], [0, 0, 0]):
+        g = ds.TracerGroup(tex, devices, width=w, height=h, **kw)
+        g.render_accumulate(1, 60)
+        g.render_accumulate(61, spp - 60)
+        assert np.array_equal(g.mean(), want[0]) and np.array_equal(g.m2(), want[1]), devices
+        assert g.counters() == want[2], devices
+        screen, avg = g.tonemap(0.4)
+        assert np.array_equal(screen, want[3][0]) and avg == want[3][1], devices
+        assert g.is_converged() == want[4] and want[4][1] > 0, devices
+        g.reset()
+        g.render_accumulate(1, 3)
+        assert g.counters()["paths"] == 3 * w * h
+        g.close()
+    with pytest.raises(_lib.CloudTraceError) as e:
+        ds.TracerGroup(tex, [0, 99], width=w, height=h, **kw)
+    assert e.value.code == _lib.CT_E_INVAL and "shard 1" in e.value.message
+    # the C++ host: cloudtrace --gpus 0,0 against the single-GPU picture
+    import subprocess
+    from deepestscatter_amd import build, exr
+    cli = build.build_cli()
+    outs = []
+    for extra in ([], ["--gpus", "0,0"]):
+        out = tmp_path / ("g" if extra else "s")
+        out.mkdir()
+        r = subprocess.run([str(cli), "procedural:32", "--size", "48x32", "--spp", "45", "--light", "Side", "--out", str(out), *extra],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(exr.read_exr(out / "procedural_32.Side.PT.exr"))
+    assert np.array_equal(outs[0], outs[1]) and outs[0].max() > 0

@@ -150,6 +150,7 @@ static int check_invariants(CtHandle h);
         if (hipSetDevice((h)->device) != hipSuccess) { \
             return fail((h), CT_E_HIP, "hipSetDevice(%d) failed", (h)->device); \
         }                                              \
+        (void)hipGetLastError(); /* a stale error of another library in this thread (RCCL leaves them) is not ours */ \
     } while (0)
 
 // Every entry point except the *_async ones first waits for the batches in flight.
@@ -296,6 +297,7 @@ static int create_impl(const CtScene *s, CtHandle h)
         return fail(h, CT_E_INVAL, "device %d out of range (0..%d)", s->device, ndev - 1);
     }
     HIPCHK(h, hipSetDevice(s->device));
+    (void)hipGetLastError(); // (see NEED_NOFLUSH)
     HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     for (auto &e : h->ev) {
@@ -366,9 +368,12 @@ static int create_impl(const CtScene *s, CtHandle h)
     if (s->estimator == CT_EST_DELTA) {
         // a tracking visit ends in a real collision 6 times out of 10: short bursts and an early refill
         // (sweep at 512^3/1024^2: 8/16 -> 2300 Msamples/s, 1/16 -> 2700, 1/4 -> 2870, 3/4 -> 3460)
-        d.march_burst = 3;
+        // (round 2, on the final kernel: 3/4 with scatter phases as soon as one lane waits 4200; the scatter phase held back
+        // until 16 lanes wait 4241; that with bursts of 2: 4295 -- profiles/r02e/delta_scatter_min_sweep.log)
+        d.march_burst = 2;
         d.burst_scatter = 48;
         d.regen_min = 4;
+        d.scatter_min = 16;
     }
     // measured (profiles/README.md): regional queues raise the L2 hit rate from 67 % to 77 % but not
     // the speed (the kernel is bound by the L1 gather rate and by instruction issue, not by L2

@@ -347,6 +347,7 @@ extern "C" int ct_group_merge(CtGroup g)
         }
     } else {
         GHIP(g, hipSetDevice(g->devices[0]));
+        (void)hipGetLastError();
         for (uint32_t i = 1; i < g->handles.size(); i++) {
             GHIP(g, hipMemcpyPeerAsync(g->scratch, g->devices[0], g->staging[i], g->devices[i], 2 * bytes, g->streams[0]));
             hipLaunchKernelGGL(add_into_kernel, dim3(1024), dim3(256), 0, g->streams[0], (float4 *)g->staging[0],

@@ -490,6 +490,16 @@ static Event delta_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCount
 static Event free_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCounters *k)
 {
     if (c->estimator == 1) {
+        /* getNextScatteringEvent only marches while isInBox(pos) (cloud.cuh:87): a flight that STARTS outside the
+         * slack box does nothing.  The bounce loops of totalRadiance / multipleScatterSunRadiance test that before every
+         * flight anyway (cloudRadianceMaterials.cu:28,91); singleScatterSunRadiance (:134) relies on the march's own
+         * loop condition, so the DELTA twin needs the test here -- the box "hit" of a camera that looks AWAY from a box
+         * right behind it starts at eye + 1e-6 * dir (cloudBBox.cu:26-33), outside the box.  (Round 2: this test was
+         * missing, the kernel had it; found by the soak as a counter-only difference, seed 3003 case 634.) */
+        if (!in_box(c, pos)) {
+            const Event e = { 0, pos, 1.0f };
+            return e;
+        }
         return delta_flight(c, seed, pos, dir, k);
     }
     const float xi = orc_rnd(seed);

@@ -1133,3 +1133,34 @@ def test_group_api_merges_shards_below_the_c_abi(tmp_path):
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         outs.append(exr.read_exr(out / "procedural_32.Side.PT.exr"))
     assert np.array_equal(outs[0], outs[1]) and outs[0].max() > 0
+
+
+def test_delta_single_scatter_from_a_camera_that_looks_away_from_the_box():
+    """Found by the armed soak (seed 3003, case 634; 53 500 cases in round 2): the reference's box test reports a hit at
+    t = 1e-6 for a ray whose BACKWARD extension meets the box (cloudBBox.cu:26-33), so a camera just outside a box it
+    looks away from starts its paths outside the slack box.  The march does nothing there (its loop condition,
+    cloud.cuh:87), and so does the DELTA kernel; the DELTA oracle twin lacked that test in singleScatterSunRadiance
+    (no bounce loop around the flight, cloudRadianceMaterials.cu:134) and walked the apron cells, counting lookups
+    that can never contribute: identical images, 5 % more density lookups.  Fixed in the oracle; this is the case."""
+    rng = np.random.default_rng(3003)
+    for _ in range(635):                                   # tools/soak.py's draws, up to the reported case
+        kw, eye = _random_scene(rng)
+        rng.random()
+        pattern = [(int(n), bool(rng.random() < 0.6)) for n in rng.integers(1, 5, 4)]
+    tex = kw.pop("tex")
+    w, h = kw.pop("width"), kw.pop("height")
+    assert (kw["mode"], kw["estimator"], tex.shape) == (2, 1, (25, 6, 28))
+    tr, orc = make_pair(tex, w, h, **kw)
+    U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
+    tr.set_camera(eye, U, V, W)
+    orc.set_camera(eye, U, V, W)
+    first = 1
+    for n, a in pattern:
+        (tr.render_accumulate_async if a else tr.render_accumulate)(first, n)
+        first += n
+    mean, m2 = orc.render(first - 1)
+    assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2)
+    assert tr.counters() == orc.counters.as_dict()
+    c = tr.counters()
+    assert c["box_hits"] < c["paths"] and c["density_lookups"] == 897531
+    tr.close()

@@ -339,7 +339,9 @@ def main():
         "bound": "hbm",
         "kernel": "render_simple_kernel" if args.simple_kernel else ("render_delta_kernel" if args.estimator else "render_persistent_kernel"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "achieved_is": "max(issued bytes, PMC traffic) per launch / average launch duration",
+        "achieved_is": "max(issued bytes, PMC traffic) per launch / average launch duration" if traffic else
+                       "issued bytes only: no PMC traffic was measured in this run (N > 1, --no-pmc-traffic or no profiler); the "
+                       "traffic-based fraction is on the N = 1 line",
         "traffic": traffic, "traffic_source": traffic_source,
         "issued_bytes_per_launch": issued_bytes / launches,
         "issued_GBps": issued_bytes / sec / 1e9 if sec > 0 else 0.0,

@@ -1,6 +1,6 @@
 """The N>1 path on CPU: two gloo ranks each hold only their pixel-tile shard of a radiance buffer
-(produced by the oracle, since there is no GPU here), and the frame reduce must rebuild the whole
-image exactly.  Exercises deepestscatter_amd.distributed.frame_reduce, the tile->shard map and the
+(produced by the oracle, since there is no GPU here) -- mean and Welford M2, stacked the way ShardedTracer
+stages them -- and the frame reduce must rebuild the whole image and its M2 exactly.  Exercises deepestscatter_amd.distributed.frame_reduce, the tile->shard map and the
 'foreign pixels are exactly zero' contract that makes SUM a merge."""
 import os
 import sys
@@ -27,10 +27,10 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
     w, h, spp = 40, 24, 3
     tex = sphere_volume(24, seed=3)
     orc = O.Oracle(tex, w, h, mode=0, threads=2)
-    mean, _ = orc.render(spp)
+    mean, m2 = orc.render(spp)
     mask = ds.shard_mask(w, h, rank, world)
-    local = mean.copy()
-    local[~mask] = 0                      # what a shard's handle holds: its tiles, zeros elsewhere
+    local = np.stack([mean, m2])          # the [2, H, W, 4] buffer ShardedTracer reduces with ONE collective
+    local[:, ~mask] = 0                   # what a shard's handle holds: its tiles, zeros elsewhere
     t = torch.from_numpy(local)
     frame_reduce(t, 0)
     # every rank also checks the partition property with an all-reduce of the masks
@@ -39,7 +39,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
     assert int(m.min()) == 1 and int(m.max()) == 1
     if rank == 0:
         np.save(os.path.join(out_dir, "merged.npy"), t.numpy())
-        np.save(os.path.join(out_dir, "whole.npy"), mean)
+        np.save(os.path.join(out_dir, "whole.npy"), np.stack([mean, m2]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,5 +51,6 @@ def test_gloo_frame_reduce_rebuilds_the_whole_frame(tmp_path, world):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     merged = np.load(tmp_path / "merged.npy")
     whole = np.load(tmp_path / "whole.npy")
-    assert np.array_equal(merged, whole)
-    assert merged[..., :3].max() > 0
+    assert merged.shape == (2, 24, 40, 4)
+    assert np.array_equal(merged, whole)            # mean AND Welford M2: the sum of disjoint shards is the whole frame
+    assert merged[0, ..., :3].max() > 0 and merged[1, ..., :3].max() > 0

@@ -170,6 +170,47 @@ def pmc_traffic(args, S):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def measured_ceilings(torch, device):
+    """The box's own ceilings, measured in this run ("use the measured ceiling as denominator too").
+    copy: a device-to-device copy of 1 GiB (read + written bytes, best of 6) -- a streaming read+write rate, which a
+    read-dominated gather that also hits the Infinity Cache can exceed.  random_line: the library's own probe
+    (ct_debug_fetch_probe: one thread per 128-B line of a 4 GiB buffer, two unaligned 8-byte loads from a pseudo-random,
+    never repeated line -- the estimator's access shape with every access a miss): lines x 128 B per second, from the
+    difference of two calls with 12 and 4 repeats (allocation and clearing cancel out)."""
+    import ctypes as C
+    from deepestscatter_amd import _lib
+    out = {}
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    b = torch.empty_like(a)
+    best = None
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None or ms < best else best
+    del a, b
+    torch.cuda.empty_cache()
+    out["copy_GBps_this_run"] = 2.0 * n * 4 / (best * 1e-3) / 1e9
+    L = _lib.load()
+    t = {}
+    for reps in (4, 12, 4, 12):
+        s_out = C.c_uint64(0)
+        t0 = time.perf_counter()
+        rc = L.ct_debug_fetch_probe(device, 25, reps, C.byref(s_out))
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            return out
+        t[reps] = min(t.get(reps, dt), dt)
+    per_repeat = (t[12] - t[4]) / 8.0
+    if per_repeat > 0:
+        out["random_128B_line_GBps_this_run"] = (1 << 25) * 128 / per_repeat / 1e9
+    return out
+
+
 def delta_leg(ds, tex, W, H, mode, S, steps):
     """The same workload with the DELTA estimator (Woodcock tracking, BASELINE.json north_star's algorithm; unbiased,
     not the reference's sampler, so it cannot be the parity path -- DESIGN.md 4.2), reported beside the headline:
@@ -333,6 +374,12 @@ def main():
                                      (": " + pmc["error"] if pmc else "") + ")"
             except Exception:
                 traffic = None
+    here = {}
+    if rank == 0 and world == 1:
+        try:
+            here = measured_ceilings(torch, local_rank)
+        except Exception:
+            here = {}
     achieved_bytes = max(issued_bytes / launches, traffic or 0.0)
     achieved = achieved_bytes * launches / sec / 1e9 if sec > 0 else 0.0
     roofline = {
@@ -350,8 +397,13 @@ def main():
         "algorithmic_over_peak": alg_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
         # measured ceilings ("use the measured ceiling as denominator too")
         "peak_measured": {"float4_copy_GBps": MEASURED_COPY_GBS, "random_128B_line_GBps": MEASURED_RANDOM_LINE_GBS,
-                          "source": "MI355X_MICROARCH.md (copy); profiles/gather_probe.txt (one random 128-B line per lane, working set >= 256 MiB)"},
+                          **here,
+                          "source": "MI355X_MICROARCH.md (copy); profiles/gather_probe.txt (one random 128-B line per lane, working set >= 256 MiB); "
+                                    "*_this_run: measured after the timed region -- a 1 GiB device-to-device copy (read + written bytes; a "
+                                    "read-dominated gather that also hits the Infinity Cache can exceed it) and the library's random-line "
+                                    "probe (4 GiB, every access a miss: the ceiling for this kernel's access shape)"},
         "frac_of_measured_copy": achieved / MEASURED_COPY_GBS,
+        "frac_of_random_line_probe_this_run": achieved / here["random_128B_line_GBps_this_run"] if here.get("random_128B_line_GBps_this_run") else None,
         "frac_of_random_line_probe": achieved / MEASURED_RANDOM_LINE_GBS,
         "avg_launch_ms": render_ms / launches, "launches": launches,
         "lookups_per_sample": lookups / max(dk["paths"], 1),
@@ -377,6 +429,9 @@ def main():
                         "(Mie multi-scatter + NEE), estimator "
                         f"{('MARCH (reference-faithful)', 'DELTA (Woodcock, LDS-resident majorant cells)')[args.estimator]}, max_depth 2000",
             "volume": args.volume, "width": W, "height": H, "spp_per_step": S,
+            # the synthetic input's value distribution
+            "density_stats": {"nonzero_fraction": float((tex > 0).mean()), "mean": float(tex.mean()), "max": int(tex.max()),
+                              "histogram_16_bins": [int(v) for v in np.bincount(tex.reshape(-1) >> 4, minlength=16)]},
             "parallelism": f"pixel-tile shard x{world}" + (" + RCCL reduce of the [mean | M2] buffer per step" if world > 1 else ""),
             "pipelined_steps": not args.sync_steps,
         },

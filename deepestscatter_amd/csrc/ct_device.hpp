@@ -254,7 +254,11 @@ CT_DEV uint2 load_footprint_m(const DevScene &sc, int32_t ix, int32_t iy, int32_
     }
     uint2 a, c;
     __builtin_memcpy(&a, p, 8);       // t_lx, t_lx+1 of row ly at bytes 0,1; of row ly+1 at 5,6; M at 4-lx
+#ifdef CT_EXPERIMENT_ONE_LOAD
+    c = a;                            // TIMING EXPERIMENT ONLY (wrong results): what a one-load footprint layout could gain
+#else
     __builtin_memcpy(&c, p + 25, 8);  // the same one z-slice up
+#endif
     meta = __builtin_amdgcn_perm(a.y, a.x, 0x0c0c0c04u - lx);
     uint2 r;
     r.x = __builtin_amdgcn_perm(a.y, a.x, 0x06050100u);
@@ -317,12 +321,16 @@ CT_DEV uint2 fetch_cell_cached(const DevScene &sc, const uint8_t *bricks, f3 p, 
     const uint32_t off = (brick << 7) | local;   // unique while there are fewer than 2^25 bricks: DevScene::nee_cache
     reused = sc.nee_cache != 0u && off == key;
     if (!reused) {
+#ifdef CT_EXPERIMENT_NO_NEE_LOAD
+        cached = make_uint2(off, off >> 3);   // TIMING EXPERIMENT ONLY (wrong radiance, same paths): the shadow-volume fetch for free
+#else
         const uint8_t *q = bricks + (((size_t)brick << 7) | local);
         uint2 a, c;
         __builtin_memcpy(&a, q, 8);
         __builtin_memcpy(&c, q + 25, 8);
         cached.x = __builtin_amdgcn_perm(a.y, a.x, 0x06050100u);
         cached.y = __builtin_amdgcn_perm(c.y, c.x, 0x06050100u);
+#endif
         key = off;
     }
     return cached;

@@ -388,6 +388,12 @@ class CloudTracer:
         check(self.L.ct_debug_suspended(self.h, C.byref(n)), self.h)
         return int(n.value)
 
+    def debug_math_selftest(self, which: int) -> dict:
+        """ct_debug_math_selftest: 0 = reciprocal, 1 = square root -> {tested, mismatches, first_bad_bits}."""
+        out = np.zeros(3, np.uint64)
+        check(self.L.ct_debug_math_selftest(self.h, which, _p(out)), self.h)
+        return {"tested": int(out[0]), "mismatches": int(out[1]), "first_bad_bits": int(out[2])}
+
     def debug_cdf_inversion(self, first_u24: int, count: int) -> np.ndarray:
         out = np.empty(count, np.uint32)
         check(self.L.ct_debug_cdf_inversion(self.h, first_u24, count, _p(out)), self.h)

@@ -2035,6 +2035,40 @@ extern "C" int ct_debug_fetch_probe(int32_t device, uint32_t log2_lines, uint32_
     return e == hipSuccess ? CT_OK : fail(nullptr, CT_E_HIP, "fetch probe failed: %s", hipGetErrorString(e));
 }
 
+extern "C" int ct_debug_math_selftest(CtHandle h, int32_t which, uint64_t out[3])
+{
+    NEED(h);
+    if (!out || (which != 0 && which != 1)) {
+        return fail(h, CT_E_INVAL, "ct_debug_math_selftest: which = 0 (reciprocal) or 1 (square root)");
+    }
+    // every float with 2^-60 <= x < 2^61 (positive: both functions are odd / undefined for negative arguments in the same way
+    // as the IEEE operations, and the kernels only pass positive values); the reciprocal also for the negative range
+    unsigned long long *d = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d, 3 * sizeof(unsigned long long)));
+    const unsigned long long init[3] = { 0, 0, 0xffffffffull };
+    hipError_t e = hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, h->stream);
+    const uint32_t lo = (127u - 60u) << 23, hi = ((127u + 61u) << 23) - 1u;
+    if (e == hipSuccess) {
+        e = launch_math_selftest(which, lo, hi, d, h->stream);
+    }
+    if (e == hipSuccess && which == 0) {
+        e = launch_math_selftest(which, lo | 0x80000000u, hi | 0x80000000u, d, h->stream);
+    }
+    unsigned long long r[3] = { 0, 0, 0 };
+    if (e == hipSuccess) {
+        e = hipMemcpyAsync(r, d, sizeof r, hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess) {
+        e = hipStreamSynchronize(h->stream);
+    }
+    hipFree(d);
+    HIPCHK(h, e);
+    out[0] = r[0];
+    out[1] = r[1];
+    out[2] = r[2];
+    return CT_OK;
+}
+
 extern "C" int ct_debug_cdf_inversion(CtHandle h, uint32_t first_u24, uint32_t count, uint32_t *k_host_out)
 {
     NEED(h);

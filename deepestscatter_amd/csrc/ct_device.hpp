@@ -32,10 +32,52 @@ CT_DEV f3 cross3(f3 a, f3 b)
 {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// IEEE reciprocal, division and square root of the bounce's arithmetic (correctly rounded: part of the numeric
+// contract).  -DCT_EXPERIMENT_FAST_DIVSQRT maps them to the one-instruction approximations for a TIMING experiment
+// (wrong results): the upper bound of what cheaper correctly-rounded sequences could gain.
+#ifdef CT_EXPERIMENT_FAST_DIVSQRT
+CT_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+CT_DEV float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+CT_DEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+CT_DEV float rcp_moderate(float x) { return __builtin_amdgcn_rcpf(x); }
+CT_DEV float sqrt_moderate(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+CT_DEV float rcp_(float x) { return 1.0f / x; }
+CT_DEV float div_(float a, float b) { return a / b; }
+CT_DEV float sqrt_(float x) { return sqrtf(x); }
+// The same correctly rounded results in fewer instructions for arguments of moderate magnitude, 2^-60 <= x <= 2^60
+// (what the bounce computes: a density, the squared length of a direction-sized vector): the hardware's 1-ulp estimate
+// plus one Newton step (two for the square root) carried out with fused multiply-adds, whose residual is exact.  hipcc's IEEE sequences spend
+// most of their ten instructions on scaling for subnormal and huge arguments, which cannot occur here.  That these
+// return the bits of 1.0f / x and sqrtf(x) for EVERY float in the range is not argued but checked, exhaustively, on the
+// device: ct_debug_math_selftest / test_fast_rcp_and_sqrt_are_correctly_rounded_for_every_float_in_range.
+CT_DEV float rcp_moderate(float x)
+{
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = fmaf(-x, r0, 1.0f);
+    return fmaf(e, r0, r0);
+}
+CT_DEV float sqrt_moderate(float x)
+{
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float h = __builtin_amdgcn_rcpf(s0 + s0);    // ~ 1 / (2 sqrt(x))
+    const float s1 = fmaf(fmaf(-s0, s0, x), h, s0);    // (the residual is exact)
+    // one step is wrong for 60 floats -- mantissa all ones, every other exponent -- so a second one
+    return fmaf(fmaf(-s1, s1, x), h, s1);
+}
+#endif
+
 // optix::normalize = v * (1.0f / sqrtf(dot(v,v)))  (OptiX SDK optixu_math_namespace.h)
 CT_DEV f3 normalize3(f3 a)
 {
-    const float inv = 1.0f / sqrtf(dot3(a, a));
+    const float inv = rcp_(sqrt_(dot3(a, a)));
+    return scale3(a, inv);
+}
+// The same for a vector whose squared length is of moderate magnitude (see rcp_moderate): the two normalisations of
+// getNewDirection, whose arguments are built from unit vectors (|b|^2 >= 1/2, |r| ~ 1).
+CT_DEV f3 normalize3_unitish(f3 a)
+{
+    const float inv = rcp_moderate(sqrt_moderate(dot3(a, a)));
     return scale3(a, inv);
 }
 
@@ -423,7 +465,7 @@ CT_DEV f3 new_direction(CdfPtr cdf, GuidePtr guide, uint32_t &seed, f3 prev)
 {
     const float cos_theta = sample_cos_theta(cdf, guide, lcg24(seed));
     const float phi = u24_to_float(lcg24(seed)) * kPi * 2;
-    const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+    const float sin_theta = sqrt_moderate(1 - cos_theta * cos_theta); // cos = (2k+1)/65536 - 1: 1 - cos^2 is in [2^-15, 1]
     float sn, cs;
     ct_sincosf(phi, &sn, &cs);
     const float px = sin_theta * cs, py = sin_theta * sn, pz = cos_theta;
@@ -434,11 +476,11 @@ CT_DEV f3 new_direction(CdfPtr cdf, GuidePtr guide, uint32_t &seed, f3 prev)
     } else {
         b = mk3(0.0f, -prev.z, prev.y);
     }
-    b = normalize3(b);
+    b = normalize3_unitish(b);
     const f3 tg = cross3(b, prev);
     // inverse_transform: p.x*tangent + p.y*binormal + p.z*normal
     const f3 r = add3(add3(scale3(tg, px), scale3(b, py)), scale3(prev, pz));
-    return normalize3(r);
+    return normalize3_unitish(r);
 }
 
 // ---- intersect, cloudBBox.cu:7-37 -----------------------------------------------------------

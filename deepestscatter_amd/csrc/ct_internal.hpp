@@ -128,6 +128,7 @@ hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subfr
                             unsigned long long *unconverged, hipStream_t stream);
 hipError_t launch_cdf_selftest(const float *cdf, const uint16_t *guide, uint32_t first_u24, uint32_t count,
                                uint32_t *k_out, hipStream_t stream);
+hipError_t launch_math_selftest(int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out, hipStream_t stream);
 hipError_t launch_fetch_probe(const uint8_t *buf, uint32_t log2_lines, uint32_t second_offset,
                               unsigned long long *sum, hipStream_t stream);
 hipError_t launch_point_rays(const DevScene &sc, const void *tasks, uint32_t n, uint32_t n_pad, float4 *primary,

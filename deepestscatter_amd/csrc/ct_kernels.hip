@@ -1035,8 +1035,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 // nearly every wave at 7 % lane occupancy.  `inv_maxd` carries the density sampled at
                 // the collision, `dfree` the brick's "interior" flag (both are reset below).
                 {
-                    const float lg = logf_above_one(xi / T);
-                    const float inv = 1.0f / inv_maxd;
+                    const float lg = logf_above_one(div_(xi, T));
+                    // (the density of a collision is of moderate magnitude: T fell at this step, so exp(-density * step) < 1,
+                    // i.e. density * step >= 2^-25; and density <= densityMultiplier < 80 / step)
+                    const float inv = rcp_moderate(inv_maxd);
                     pos = sub3(pos, scale3(scale3(dir, lg), inv)); // scatterPos, :99
                 }
                 // isInBox(scatterPos), cloudRadianceMaterials.cu:49-52
@@ -1434,11 +1436,11 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
     const float edge = (float)(1 << sc.mc_shift);
     auto axis = [&](int32_t B, float TP, float V, float &TMAX, float &TDELTA) {
         if (V > 0.0f) {
-            const float inv = 1.0f / V; // one division per axis, as in the oracle
+            const float inv = rcp_(V); // one division per axis, as in the oracle
             TMAX = ((float)(((B + 1) << sc.mc_shift) - sc.brick_bias) - TP) * inv;
             TDELTA = edge * inv;
         } else if (V < 0.0f) {
-            const float inv = 1.0f / V;
+            const float inv = rcp_(V);
             TMAX = ((float)((B << sc.mc_shift) - sc.brick_bias) - TP) * inv;
             TDELTA = edge * -inv;
         } else {
@@ -2509,6 +2511,45 @@ hipError_t launch_cdf_selftest(const float *cdf, const uint16_t *guide, uint32_t
 {
     hipLaunchKernelGGL(cdf_selftest_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, cdf, guide, first_u24,
                        count, k_out);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// self-test hook: rcp_moderate / sqrt_moderate against the IEEE operations for EVERY float of their range
+// =============================================================================================
+// out[0] = inputs tested, out[1] = mismatches, out[2] = smallest mismatching bit pattern (0xffffffff: none)
+__global__ void math_selftest_kernel(int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out)
+{
+    unsigned long long tested = 0, bad = 0;
+    uint32_t first = 0xffffffffu;
+    const uint64_t total = (uint64_t)hi_bits - lo_bits + 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t bits = lo_bits + (uint32_t)i;
+        const float x = __uint_as_float(bits);
+        float got, want;
+        if (which == 0) {
+            got = rcp_moderate(x);
+            want = 1.0f / x;
+        } else {
+            got = sqrt_moderate(x);
+            want = sqrtf(x);
+        }
+        tested += 1;
+        if (__float_as_uint(got) != __float_as_uint(want)) {
+            bad += 1;
+            first = min(first, bits);
+        }
+    }
+    atomicAdd(&out[0], tested);
+    if (bad) {
+        atomicAdd(&out[1], bad);
+        atomicMin(&out[2], (unsigned long long)first);
+    }
+}
+
+hipError_t launch_math_selftest(int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(math_selftest_kernel, dim3(4096), dim3(256), 0, stream, which, lo_bits, hi_bits, out);
     return hipGetLastError();
 }
 

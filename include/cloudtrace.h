@@ -349,6 +349,11 @@ CT_API int ct_debug_memory(CtHandle h, uint64_t out[8]);
  * load to byte 85 so that both 64-byte halves of the line are touched.  Returns a checksum. */
 CT_API int ct_debug_fetch_probe(int32_t device, uint32_t log2_lines, uint32_t repeats, uint64_t *sum_out);
 
+/* Self-test hook: the kernels' short correctly-rounded reciprocal (which = 0) and square root (which = 1) against the IEEE
+ * operations for EVERY float of their range, 2^-60 <= |x| < 2^61 (reciprocal: both signs), on the device:
+ * out[0] = floats tested, out[1] = mismatches (must be 0), out[2] = smallest mismatching bit pattern or 0xffffffff. */
+CT_API int ct_debug_math_selftest(CtHandle h, int32_t which, uint64_t out[3]);
+
 /* Self-test hook: k(val) of the CDF inversion (cloud.cuh:162-180) for `count` consecutive 24-bit
  * random integers starting at first_u24, evaluated by the device code; cos(theta) = (2k+1)/65536-1. */
 CT_API int ct_debug_cdf_inversion(CtHandle h, uint32_t first_u24, uint32_t count, uint32_t *k_host_out);

@@ -1436,7 +1436,9 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
     const float edge = (float)(1 << sc.mc_shift);
     auto axis = [&](int32_t B, float TP, float V, float &TMAX, float &TDELTA) {
         if (V > 0.0f) {
-            const float inv = rcp_(V); // one division per axis, as in the oracle
+            // one division per axis, as in the oracle.  (IEEE sequence: V can be arbitrarily small; a range test in front of
+            // the short sequence measured 4372 instead of 4450 Msamples/s)
+            const float inv = rcp_(V);
             TMAX = ((float)(((B + 1) << sc.mc_shift) - sc.brick_bias) - TP) * inv;
             TDELTA = edge * inv;
         } else if (V < 0.0f) {

@@ -1136,7 +1136,7 @@ def test_group_api_merges_shards_below_the_c_abi(tmp_path):
 
 
 def test_delta_single_scatter_from_a_camera_that_looks_away_from_the_box():
-    """Found by the armed soak (seed 3003, case 634; 53 500 cases in round 2): the reference's box test reports a hit at
+    """Found by the armed soak (seed 3003, case 634; 61 500 cases in round 2): the reference's box test reports a hit at
     t = 1e-6 for a ray whose BACKWARD extension meets the box (cloudBBox.cu:26-33), so a camera just outside a box it
     looks away from starts its paths outside the slack box.  The march does nothing there (its loop condition,
     cloud.cuh:87), and so does the DELTA kernel; the DELTA oracle twin lacked that test in singleScatterSunRadiance

@@ -1434,21 +1434,16 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
     d.bz = (floor_to_int(tpz) + sc.brick_bias) >> sc.mc_shift;
     const float inf = __uint_as_float(0x7f800000u);
     const float edge = (float)(1 << sc.mc_shift);
+    // One division per axis and NO branch around it: the lanes of a wave disagree about the sign of V, so an
+    // if / else-if with a division in each arm made every wave execute both (six IEEE divisions per set-up).  The values
+    // are the oracle's: inv = 1 / V; V > 0: tmax = (upper bound - tp) * inv, tdelta = edge * inv; V < 0: tmax = (lower
+    // bound - tp) * inv, tdelta = edge * -inv = edge * |inv|; V == 0: both infinite.
     auto axis = [&](int32_t B, float TP, float V, float &TMAX, float &TDELTA) {
-        if (V > 0.0f) {
-            // one division per axis, as in the oracle.  (IEEE sequence: V can be arbitrarily small; a range test in front of
-            // the short sequence measured 4372 instead of 4450 Msamples/s)
-            const float inv = rcp_(V);
-            TMAX = ((float)(((B + 1) << sc.mc_shift) - sc.brick_bias) - TP) * inv;
-            TDELTA = edge * inv;
-        } else if (V < 0.0f) {
-            const float inv = rcp_(V);
-            TMAX = ((float)((B << sc.mc_shift) - sc.brick_bias) - TP) * inv;
-            TDELTA = edge * -inv;
-        } else {
-            TMAX = inf;
-            TDELTA = inf;
-        }
+        const float inv = rcp_(V);
+        const int32_t bound = ((B + (V > 0.0f ? 1 : 0)) << sc.mc_shift) - sc.brick_bias;
+        const bool moving = V != 0.0f;
+        TMAX = moving ? ((float)bound - TP) * inv : inf;
+        TDELTA = moving ? edge * fabsf(inv) : inf;
     };
     axis(d.bx, tpx, vx, d.tmax.x, d.tdelta.x);
     axis(d.by, tpy, vy, d.tmax.y, d.tdelta.y);

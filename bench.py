@@ -10,8 +10,8 @@ reduce of the accumulated radiance buffer).
 A "step" = the 1024-spp job of BASELINE.json configs[2]/[3]: --spp-per-step (default 1024) subframes of the whole
 frame, whatever N is ("scaling": "strong" -- rank r renders its 1/N of the 8x8-pixel tiles for all 1024 subframes):
 estimator kernel(s) + Welford accumulate kernel(s), plus (N>1) ONE RCCL SUM-reduce of the merged [mean | M2]
-buffer (2 x W*H float4) to rank 0.  At N=1 a step is two launches of 512 subframes (what the 8 GiB per-batch sample
-scratch holds at 1024^2); at N=8 one launch of 1024 subframes over an eighth of the pixels.  --weak gives every
+buffer (2 x W*H float4) to rank 0.  At N=1 a step is one launch of 1024 subframes (14 GB of per-sample scratch, which a
+16 GiB slot holds at 1024^2); at N=8 one launch of 1024 subframes over an eighth of the pixels.  --weak gives every
 GPU the same work per step instead (512 x N subframes per step: round 1's definition).  (The reference updates its display
 every 10 subframes and saves every 40, Camera.cpp:189,211; a launch ends with a tail of waves that
 finish its long paths unless it may hand them to the next launch, which is what the enqueued steps of this
@@ -368,8 +368,9 @@ def main():
             try:
                 rec = json.loads(f.read_text())
                 lc = rec.get("launch_config", {})
-                if (lc.get("volume"), lc.get("width"), lc.get("height")) == (args.volume, W, H) and S % lc.get("spp_per_launch", 512) == 0:
-                    traffic = rec.get("hbm_bytes_per_launch")
+                if (lc.get("volume"), lc.get("width"), lc.get("height")) == (args.volume, W, H):
+                    # (the committed figure is per launch of lc.spp_per_launch subframes; traffic is proportional to the samples)
+                    traffic = rec.get("hbm_bytes_per_launch") * (S * args.steps / launches) / lc.get("spp_per_launch", 512)
                     traffic_source = "profiles/pmc_latest.json (committed rocprofv3 --pmc run of this command; not measured in this run" + \
                                      (": " + pmc["error"] if pmc else "") + ")"
             except Exception:

@@ -120,6 +120,21 @@ def test_no_cpu_fallback_without_a_device(product_lib):
     assert "no CPU fallback" in e.value.message
 
 
+def test_group_api_without_a_device_and_with_bad_arguments(product_lib):
+    """ct_group_*: argument errors come back as CtStatus codes with a message, and without a GPU the group fails like a
+    single handle does (no CPU fallback, no exception across the ABI)."""
+    with pytest.raises(_lib.CloudTraceError) as e:
+        ds.TracerGroup(sphere_volume(16), [], width=16, height=16)
+    assert e.value.code == _lib.CT_E_INVAL
+    if not _has_gpu():
+        with pytest.raises(_lib.CloudTraceError) as e:
+            ds.TracerGroup(sphere_volume(16), [0, 1], width=16, height=16)
+        assert e.value.code == _lib.CT_E_NODEVICE and "shard 0" in e.value.message and "no CPU fallback" in e.value.message
+    assert product_lib.ct_group_destroy(None) == 0
+    n = C.c_uint32(0)
+    assert product_lib.ct_group_size(None, C.byref(n)) == _lib.CT_E_INVAL
+
+
 def test_product_does_not_reference_the_oracle():
     """The oracle is test infrastructure: nothing under deepestscatter_amd/ may include, import,
     link or dlopen anything from oracle/."""

@@ -386,3 +386,26 @@ def test_delta_lower_bound_codes_only_skip_lookups():
     assert np.array_equal(mean, mean2) and np.array_equal(m2, m22)
     assert with_bound["scatter_events"] == without["scatter_events"]
     assert with_bound["density_lookups"] < without["density_lookups"]
+
+
+def test_delta_flight_that_starts_outside_the_slack_box_does_nothing():
+    """The DELTA oracle twin applies the march's loop condition (cloud.cuh:87) to a flight as a whole: from a start
+    outside the slack box -- the reference's box test reports such "hits" for a camera that looks away from a box
+    right behind it (cloudBBox.cu:26-33) -- it makes no lookup and does not scatter, in singleScatterSunRadiance too,
+    which has no bounce loop around the flight (cloudRadianceMaterials.cu:134).  Round 2's soak found the missing test
+    as 5 % too many density lookups with identical images (seed 3003 case 634).  Here: a dense volume without a zero
+    border (so the apron cells outside it have non-zero majorants), the eye just below it, looking straight down."""
+    import _oracle as O
+    tex = np.full((8, 6, 10), 160, np.uint8)
+    w, h = 12, 16
+    eye = (-0.2, -0.40, 0.3)                      # box half extents (0.5, 0.3, 0.4): 0.1 below the box
+    for est in (0, 1):
+        for mode in (0, 1, 2):
+            orc = O.Oracle(tex, w, h, mode=mode, estimator=est, cloud_size_m=400.0, max_depth=17)
+            U, V, W = O.camera_variables(eye, lookat=(-0.2, -3.0, 0.3), up=(0.0, 0.0, 1.0), aspect=w / h)
+            orc.set_camera(eye, U, V, W)
+            mean, _ = orc.render(3)
+            c = orc.counters.as_dict()
+            assert c["box_hits"] == c["paths"] == 3 * w * h, (est, mode, c)     # every ray's backward extension meets the box
+            assert c["density_lookups"] == 0 and c["scatter_events"] == 0, (est, mode, c)
+            assert np.all(mean[..., :3] == 0)

@@ -125,7 +125,7 @@ def pmc_traffic(args, S):
         for counters in (["FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]):
             d = os.path.join(tmp, counters[0])
             r = subprocess.run([exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
-                               capture_output=True, text=True, timeout=420)
+                               capture_output=True, text=True, timeout=150)
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
                 return {"error": f"rocprofv3 --pmc {' '.join(counters)} failed ({r.returncode}): {(r.stderr or r.stdout)[-300:]}"}

@@ -124,8 +124,18 @@ def pmc_traffic(args, S):
     try:
         for counters in (["FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]):
             d = os.path.join(tmp, counters[0])
-            r = subprocess.run([exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
-                               capture_output=True, text=True, timeout=150)
+            # (its own process group: on a timeout the profiler AND the child it started are ended, or the child would
+            # share the GPU with the timed region)
+            proc = subprocess.Popen([exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                so, se = proc.communicate(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.communicate()
+                return {"error": f"rocprofv3 --pmc {' '.join(counters)} did not finish within 150 s"}
+            r = subprocess.CompletedProcess(proc.args, proc.returncode, so, se)
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
                 return {"error": f"rocprofv3 --pmc {' '.join(counters)} failed ({r.returncode}): {(r.stderr or r.stdout)[-300:]}"}

@@ -103,7 +103,7 @@ def cpu_baseline(tex, ins, width, height, mode, target_s):
 def pmc_traffic(args, S):
     """roofline.traffic, measured live: two short child runs of this same command under `rocprofv3 --pmc` (FETCH_SIZE
     and WRITE_SIZE need separate passes: MI355X_MICROARCH.md, HBM section), started BEFORE this process touches the
-    GPU.  Returns bytes across the L2's memory side for one full launch of `launch_spp` subframes and for one
+    GPU.  Returns bytes across the L2's memory side for one full launch of the timed step and for one
     resume-only launch, FETCH_SIZE doubled (the guide's gfx950 correction, re-calibrated on this kernel's access
     pattern by tools/fetch_probe.py: 64 B reported per 128-B line) -- or None when the profiler cannot run here."""
     import csv
@@ -114,7 +114,7 @@ def pmc_traffic(args, S):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(exe).exists() or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("CT_BENCH_CHILD"):
         return None
-    # (one step of the child is S subframes; the library cuts it into launches of at most 512 at 1024^2)
+    # (one step of the child is S subframes: one launch when its per-sample scratch fits a slot, else several equal ones)
     child = [sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-delta-leg",
              "--no-pmc-traffic", "--volume", str(args.volume), "--width", str(args.width), "--height", str(args.height),
              "--spp-per-step", str(S), "--mode", str(args.mode), "--estimator", str(args.estimator)]
@@ -290,8 +290,8 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     def step(first):
-        # estimator + accumulate on this rank's tiles, then (N>1) the RCCL SUM-reduce of the W*H float4
-        # radiance buffer to rank 0: tiles are disjoint, so the sum is an exact merge.  Steps are enqueued
+        # estimator + accumulate on this rank's tiles, then (N>1) the RCCL SUM-reduce of the [mean | M2] buffer
+        # (2 x W*H float4) to rank 0: tiles are disjoint, so the sum is an exact merge.  Steps are enqueued
         # (ct_render_accumulate_async): a launch hands its surviving paths to the next one instead of ending
         # with a tail of waves that carry a few long paths each, so the accumulate kernel of step k (and, N>1,
         # the copy + reduce of its running mean) runs behind the launch of step k+1 and the fence at the end

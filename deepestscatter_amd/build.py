@@ -49,7 +49,7 @@ CLI = HOST / "cloudtrace"
 
 def build_cli(force: bool = False, verbose: bool = False) -> Path:
     """The C++ host mirror of the reference's scene classes + headless CLI (g++, links the C ABI)."""
-    srcs = [HOST / "main.cpp", HOST / "Cameras.h", HOST / "Scene.h", HOST / "SceneDescription.h", HOST / "VdbReader.h",
+    srcs = [HOST / "main.cpp", HOST / "Cameras.h", HOST / "Scene.h", HOST / "SceneDescription.h", HOST / "VdbReader.h", HOST / "Collectors.h",
             ROOT / "include" / "cloudtrace.h"]
     if not force and CLI.exists() and LIB.exists() and all(s.stat().st_mtime <= CLI.stat().st_mtime for s in srcs + [LIB]):
         return CLI

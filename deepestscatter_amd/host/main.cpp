@@ -6,13 +6,18 @@
 //   cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light Side|Back|Front]
 //              [--size-m 7000] [--out DIR] [--data DIR] [--unfused] [--display] [--estimator march|delta] [--format exr|pfm]
 //              [--gpus N | --gpus a,b,c]   one process, one shard of 8x8-pixel tiles per GPU, RCCL reduce of [mean | M2] (ct_group_*)
-//   <cloud> = procedural:<N>[:<seed>] | file.f32grid
+//   <cloud> = file.vdb | procedural:<N>[:<seed>] | file.f32grid
+//
+//   cloudtrace collect <cloud> [--scene-id I] [--batch 2048] [--light L] [--size-m M] [--out DIR] [--data DIR] [--estimator ..]
+//              = Tasks::collect (Tasks.cpp:114-155) for one SceneSetup: the ScatterSample, Result and DisneyDescriptor
+//              collectors one after the other over records [I * batch, (I + 1) * batch), written as flat tables
 #include <chrono>
 #include <cstring>
 #include <functional>
 #include <queue>
 
 #include "Cameras.h"
+#include "Collectors.h"
 
 using namespace DeepestScatter;
 
@@ -49,7 +54,48 @@ namespace
         bool display = false;                                                     // --display: tonemap + convergence test after every update, like the GUI
         int estimator = CT_EST_MARCH;                                             // --estimator delta: Woodcock tracking (not the reference's sampler)
         std::vector<int32_t> devices;                                             // --gpus N | --gpus a,b,c: pixel-tile shards, RCCL frame reduce (ct_group_*)
+        bool collect = false;                                                     // `cloudtrace collect ...`
+        int32_t sceneId = 0;
+        uint32_t batch = 2048;                                                    // Tasks.cpp:137
     };
+
+    // Tasks::collect (Tasks.cpp:114-155) for one scene setup, with the three collectors the dataset pipeline chains:
+    // installSceneSetup(sceneSetup, cloudRoot, SunMultipleScatter, Mipmaps::On), BatchSettings(i * 2048, 2048), EmptyRenderer.
+    int collectScene(const Options& opt)
+    {
+        auto context = std::make_shared<Context>();
+        context->devices = opt.devices.empty() ? std::vector<int32_t>{} : std::vector<int32_t>{ opt.devices[0] };
+        auto resources = std::make_shared<Resources>(context);
+        const LightDirection light = opt.lights.front();
+        const float3 direction = normalize(getLightDirection(light));
+        SceneDescription scene{
+            Cloud{ Cloud::Rendering{ 1.0f / 512.f, Cloud::Rendering::Mode::SunMultipleScatter },
+                   Cloud::Model{ opt.cloud, Cloud::Model::Mipmaps::On, Cloud::Model::Size{ Meter{ opt.sizeM } } } },
+            DirectionalLight{ direction, Color{ 1, 1, 1 }, 1e6f } };
+        auto sun = std::make_shared<Sun>(std::make_shared<DirectionalLight>(scene.light), context);
+        auto cloud = std::make_shared<VDBCloud>(std::make_shared<Cloud::Model>(scene.cloud.model), context, resources);
+        auto material = std::make_shared<CloudMaterial>(std::make_shared<Cloud::Rendering>(scene.cloud.rendering), context);
+        Resources::loadMie(opt.dataDir, context->mie, context->choppedMie);
+        for (const std::shared_ptr<SceneItem>& item : std::vector<std::shared_ptr<SceneItem>>{ sun, cloud, material }) item->init();
+        createCollectorHandle(*context, opt.estimator);
+
+        auto dataset = std::make_shared<Dataset>();
+        dataset->batchAppend("SceneSetup", { Persistance::sceneSetup(opt.cloud, opt.sizeM, scene.light.direction.data()) }, opt.sceneId);
+        const BatchSettings settings((uint32_t)opt.sceneId * opt.batch, opt.batch);
+        std::vector<std::shared_ptr<SceneItem>> collectors{
+            std::make_shared<ScatterSampleCollector>(context, dataset, settings, opt.sceneId),
+            std::make_shared<RadianceCollector>(context, dataset, settings),
+            std::make_shared<DisneyDescriptorCollector>(context, dataset, settings) };
+        for (const auto& c : collectors)                                          // each is its own task in the reference: init, update until completed
+        {
+            c->init();
+            while (!c->isCompleted()) c->update();
+        }
+        dataset->save(opt.outDir);
+        std::cout << "wrote " << dataset->getRecordsCount("ScatterSample") << " ScatterSample, " << dataset->getRecordsCount("Result")
+                  << " Result, " << dataset->getRecordsCount("DisneyDescriptor") << " DisneyDescriptor records to " << opt.outDir << std::endl;
+        return 0;
+    }
 
     using LazyTask = std::function<std::shared_ptr<Scene>()>;
 
@@ -92,9 +138,18 @@ int main(int argc, char* argv[])
     {
         Options opt;
         if (argc < 2) { std::cerr << "usage: cloudtrace <cloud> [--size WxH] [--spp N] [--mode total|multi|single] [--light L] [--size-m M] [--out DIR] [--data DIR] [--unfused] [--display] [--estimator march|delta] [--format exr|pfm] [--gpus N|a,b,c]\n"; return 2; }
+        int first = 2;
         opt.cloud = argv[1];
+        if (opt.cloud == "collect")
+        {
+            if (argc < 3) throw std::invalid_argument("cloudtrace collect <cloud> ...");
+            opt.collect = true;
+            opt.cloud = argv[2];
+            opt.lights = { LightDirection::Side };
+            first = 3;
+        }
         opt.dataDir = (std::filesystem::path(argv[0]).parent_path() / ".." / "data").string();
-        for (int i = 2; i < argc; i++)
+        for (int i = first; i < argc; i++)
         {
             const std::string a = argv[i];
             auto next = [&]() { if (i + 1 >= argc) throw std::invalid_argument("missing value for " + a); return std::string(argv[++i]); };
@@ -104,6 +159,8 @@ int main(int argc, char* argv[])
             else if (a == "--out") opt.outDir = next();
             else if (a == "--data") opt.dataDir = next();
             else if (a == "--unfused") opt.fused = false;
+            else if (a == "--scene-id") opt.sceneId = std::stoi(next());
+            else if (a == "--batch") opt.batch = (uint32_t)std::stoul(next());
             else if (a == "--gpus")
             {
                 // "N" = devices 0..N-1; "a,b,c" = that list (a device may repeat: a rehearsal of N shards on fewer GPUs)
@@ -137,6 +194,8 @@ int main(int argc, char* argv[])
             }
             else throw std::invalid_argument("unknown option " + a);
         }
+
+        if (opt.collect) return collectScene(opt);
 
         std::queue<LazyTask> tasks;                                               // Tasks::renderCloud, Tasks.cpp:104-112
         for (auto l : opt.lights) tasks.push(renderCloudSingleTask(opt, l));

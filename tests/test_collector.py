@@ -202,3 +202,115 @@ def test_disney_descriptor_collector_with_oracle_backend():
         assert np.array_equal(col.decode_disney_descriptor(blob), w)
     with pytest.raises(ValueError):
         col.encode_disney_descriptor(np.zeros(7, np.uint8))
+
+
+def test_cpp_host_wire_format_and_dataset_equal_the_python_mirror(tmp_path):
+    """host/Collectors.h (the C++ mirror of the reference's collectors) encodes Result, ScatterSample, SceneSetup and
+    DisneyDescriptor records and writes its flat tables exactly like deepestscatter_amd/collector.py, whose encoders are
+    checked against the protobuf runtime above: a small C++ program is compiled here and its output compared."""
+    import subprocess
+    from pathlib import Path
+    from deepestscatter_amd import build
+    root = Path(__file__).resolve().parents[1]
+    build.build()
+    src = tmp_path / "t.cpp"
+    src.write_text(r"""
+#include "Collectors.h"
+using namespace DeepestScatter;
+int main(int argc, char** argv)
+{
+    Dataset d;
+    const float p[3] = { 0.5f, 0.0f, -1.25f }, v[3] = { 0.0f, 1.0f, 0.0f }, z[3] = { 0.f, 0.f, 0.f };
+    d.batchAppend("ScatterSample", { Persistance::scatterSample(7, p, v), Persistance::scatterSample(0, z, z), Persistance::scatterSample(-3, v, p) }, 4096);
+    d.batchAppend("Result", { Persistance::result(1.5f, true), Persistance::result(0.0f, false), Persistance::result(3.25e-3f, true) }, 10);
+    std::vector<uint8_t> grid(CT_DESCRIPTOR_BYTES);
+    for (size_t i = 0; i < grid.size(); i++) grid[i] = (uint8_t)(i * 7 + 3);
+    d.batchAppend("DisneyDescriptor", { Persistance::disneyDescriptor(grid.data(), grid.size()) }, 2);
+    const float l[3] = { -0.03f, -0.25f, 0.8f };
+    d.batchAppend("SceneSetup", { Persistance::sceneSetup("clouds/a.vdb", 7000.f, l) }, 0);
+    float rp[3], rv[3];
+    Persistance::readScatterSample(d.getRecord("ScatterSample", 4098), rp, rv);
+    if (rp[1] != 1.0f || rv[2] != -1.25f || rv[1] != 0.0f) return 3;
+    CtPointRadianceTask a{}, b{};
+    a.id = b.id = 5; a.experimentCount = 300; b.experimentCount = 100; a.radiance = 0.25f; b.radiance = 0.75f; a.runningVariance = 2.f; b.runningVariance = 1.f;
+    RadianceCollector::merge(a, b);
+    std::printf("%u %.9g %.9g %.9g %.9g\n", a.experimentCount, a.radiance, a.runningVariance, RadianceCollector::absoluteConfidenceInterval(a),
+                RadianceCollector::relativeConfidenceInterval(a));
+    d.save(argv[1]);
+    return 0;
+}
+""")
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", str(root / "deepestscatter_amd" / "host"), "-o", str(exe), str(src),
+                    f"-L{root / 'deepestscatter_amd'}", "-lcloudtrace", f"-Wl,-rpath,{root / 'deepestscatter_amd'}"], check=True)
+    out = tmp_path / "tables"
+    r = subprocess.run([str(exe), str(out)], capture_output=True, text=True, check=True)
+    recs = {t: col.read_flat_dataset(out / f"{t}.flat") for t in ("ScatterSample", "Result", "DisneyDescriptor", "SceneSetup")}
+    assert recs["ScatterSample"] == ("ScatterSample", [(4096, col.encode_scatter_sample(7, (0.5, 0.0, -1.25), (0.0, 1.0, 0.0))),
+                                                       (4097, col.encode_scatter_sample(0, (0, 0, 0), (0, 0, 0))),
+                                                       (4098, col.encode_scatter_sample(-3, (0.0, 1.0, 0.0), (0.5, 0.0, -1.25)))])
+    assert recs["Result"] == ("Result", [(10, col.encode_result(1.5, True)), (11, col.encode_result(0.0, False)), (12, col.encode_result(3.25e-3, True))])
+    grid = ((np.arange(2250) * 7 + 3) & 255).astype(np.uint8)
+    assert recs["DisneyDescriptor"] == ("DisneyDescriptor", [(2, col.encode_disney_descriptor(grid))])
+    # SceneSetup { string cloud_path = 1; float cloud_size_m = 2; Vector3 light_direction = 3; } against the protobuf runtime
+    try:
+        from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+        fd = descriptor_pb2.FileDescriptorProto(name="s.proto", package="Persistance", syntax="proto3")
+        v3 = fd.message_type.add(name="Vector3")
+        for i, n in enumerate("xyz"):
+            v3.field.add(name=n, number=i + 1, type=2, label=1)
+        m = fd.message_type.add(name="SceneSetup")
+        m.field.add(name="cloud_path", number=1, type=9, label=1)
+        m.field.add(name="cloud_size_m", number=2, type=2, label=1)
+        m.field.add(name="light_direction", number=3, type=11, label=1, type_name=".Persistance.Vector3")
+        pool = descriptor_pool.DescriptorPool()
+        pool.Add(fd)
+        SceneSetup = message_factory.GetMessageClass(pool.FindMessageTypeByName("Persistance.SceneSetup"))
+        want = SceneSetup(cloud_path="clouds/a.vdb", cloud_size_m=7000.0)
+        want.light_direction.x, want.light_direction.y, want.light_direction.z = -0.03, -0.25, 0.8
+        assert recs["SceneSetup"][1] == [(0, want.SerializeToString())]
+    except ImportError:
+        pass
+    # PointRadianceTask::operator+= and the confidence intervals: the same floats as the Python mirror
+    a = np.zeros(1, ds.POINT_TASK_DTYPE)[0]
+    b = np.zeros(1, ds.POINT_TASK_DTYPE)[0]
+    a["id"] = b["id"] = 5
+    a["experimentCount"], b["experimentCount"] = 300, 100
+    a["radiance"], b["radiance"], a["runningVariance"], b["runningVariance"] = 0.25, 0.75, 2.0, 1.0
+    col.merge_tasks(a, b)
+    got = r.stdout.split()
+    assert int(got[0]) == int(a["experimentCount"]) == 400
+    assert np.float32(got[1]) == a["radiance"] and np.float32(got[2]) == a["runningVariance"]
+    assert np.float32(got[3]) == col.absolute_confidence_interval(a["radiance"], a["runningVariance"], a["experimentCount"])
+    assert np.float32(got[4]) == col.relative_confidence_interval(a["radiance"], a["runningVariance"], a["experimentCount"])
+
+
+@pytest.mark.gpu
+def test_cpp_cli_collect_equals_the_python_pipeline(tmp_path):
+    """`cloudtrace collect` (Tasks::collect for one scene setup: ScatterSampleCollector, RadianceCollector,
+    DisneyDescriptorCollector over one batch, host/Collectors.h) writes the same tables, byte for byte, as the Python
+    mirror driving the same C ABI."""
+    import subprocess
+    from deepestscatter_amd import build
+    cli = build.build_cli()
+    batch, scene_id = 96, 3
+    out = tmp_path / "tables"
+    r = subprocess.run([str(cli), "collect", "procedural:48", "--batch", str(batch), "--scene-id", str(scene_id), "--light", "Back",
+                        "--out", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Finished writing emissions." in r.stdout and f"converged: {batch} of {batch}" in r.stdout
+    tex = ds.make_procedural_cloud(48)
+    tr = ds.CloudTracer(tex, width=64, height=64, mode=1, light_direction=ds.LIGHT_DIRECTIONS["Back"])   # SunMultipleScatter, Tasks.cpp:135
+    start = scene_id * batch
+    pos, view = tr.generate_scatter_samples(batch, start)
+    samples = [(start + i, col.encode_scatter_sample(scene_id, pos[i], view[i])) for i in range(batch)]
+    assert col.read_flat_dataset(out / "ScatterSample.flat") == ("ScatterSample", samples)
+    rc = col.RadianceCollector(tr.point_radiance_launch, pos, view, batch_start_id=start)
+    while not rc.is_completed():
+        rc.update()
+    assert col.read_flat_dataset(out / "Result.flat") == ("Result", rc.results())
+    dc = col.DisneyDescriptorCollector(tr.collect_descriptors, [s for _, s in samples], batch_start_id=start)
+    assert col.read_flat_dataset(out / "DisneyDescriptor.flat") == ("DisneyDescriptor", dc.results())
+    table, setup = col.read_flat_dataset(out / "SceneSetup.flat")
+    assert table == "SceneSetup" and len(setup) == 1 and setup[0][0] == scene_id and b"procedural:48" in setup[0][1]
+    tr.close()

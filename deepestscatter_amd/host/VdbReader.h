@@ -16,7 +16,8 @@
 //
 // No .vdb asset ships with the reference and none exists on the build image, so this reader has never seen a file
 // written by Houdini or by OpenVDB itself: it is validated against files produced by an independent minimal writer
-// (tests/_vdb.py, written from the same format description) -- tests/test_vdb.py.
+// (tests/_vdb.py, written from the same format description; its Blosc frames also with LZ4 streams from the system's
+// real liblz4) -- tests/test_vdb.py.
 #pragma once
 
 #include <zlib.h>

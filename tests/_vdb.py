@@ -4,9 +4,10 @@ Test infrastructure: it produces the inputs that tests/test_vdb.py feeds to the 
 (deepestscatter_amd/host/VdbReader.h via ct_load_vdb).  It was written from the published description of the
 format (OpenVDB io/Archive.cc, tree/RootNode.h / InternalNode.h / LeafNode.h writeTopology + writeBuffers,
 io/Compression.h writeCompressedValues, zipToStream / bloscToStream, the Blosc 1.x frame and the LZ4 block format),
-not from the reader; it shares no code with it.  No OpenVDB, Blosc or LZ4 library exists on the image, so the
-Blosc/LZ4 ENCODER below is this file's own (greedy hash matcher); what it emits are valid frames of those formats, but
-no file here has been written by OpenVDB or Houdini.
+not from the reader; it shares no code with it.  No OpenVDB or Blosc library exists on the image, so the Blosc
+container and the LZ4 encoder below are this file's own (greedy hash matcher); liblz4's runtime library IS there, and
+the tests use it to cross-check both directions (the real decoder reads this encoder's streams; the product's reader
+reads frames whose LZ4 streams the real encoder wrote).  No file here has been written by OpenVDB or Houdini.
 
     write_vdb(path, values, active, origin=(ox, oy, oz), ...)
 values / active: dense numpy arrays indexed [x, y, z] (float32 / bool) placed at index-space `origin`; every 8^3 leaf
@@ -67,6 +68,39 @@ def lz4_encode(data: bytes) -> bytes:
     return bytes(out)
 
 
+# ---- the system's own liblz4 (runtime library only; present on the image), when available: the REAL encoder/decoder ----
+def system_lz4():
+    """-> (compress(bytes) -> bytes, decompress(bytes, n) -> bytes) bound to liblz4.so.1, or None."""
+    import ctypes as C
+    try:
+        L = C.CDLL("liblz4.so.1")
+    except OSError:
+        return None
+    L.LZ4_compressBound.restype = C.c_int
+    L.LZ4_compressBound.argtypes = [C.c_int]
+    L.LZ4_compress_default.restype = C.c_int
+    L.LZ4_compress_default.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.LZ4_decompress_safe.restype = C.c_int
+    L.LZ4_decompress_safe.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+
+    def compress(data: bytes) -> bytes:
+        cap = L.LZ4_compressBound(len(data))
+        dst = C.create_string_buffer(cap)
+        n = L.LZ4_compress_default(data, dst, len(data), cap)
+        assert n > 0
+        return dst.raw[:n]
+
+    def decompress(data: bytes, n: int) -> bytes:
+        dst = C.create_string_buffer(max(n, 1))
+        got = L.LZ4_decompress_safe(data, dst, len(data), n)
+        assert got == n, (got, n)
+        return dst.raw[:n]
+    return compress, decompress
+
+
+LZ4_ENCODER = None   # set to system_lz4()[0] to have blosc_encode use the real library's streams
+
+
 # ---- Blosc 1.x frame with the LZ4 codec and byte shuffle (what OpenVDB's bloscToStream asks Blosc for) -------------
 def blosc_encode(data: bytes, typesize: int = 4, blocksize: int = 0, memcpy: bool = False, shuffle: bool = True) -> bytes:
     n = len(data)
@@ -89,7 +123,7 @@ def blosc_encode(data: bytes, typesize: int = 4, blocksize: int = 0, memcpy: boo
         body = bytearray()
         for j in range(nsplits):
             chunk = raw[j * ne:(j + 1) * ne]
-            enc = lz4_encode(chunk)
+            enc = (LZ4_ENCODER or lz4_encode)(chunk)
             if len(enc) >= ne:                          # stored: a stream as long as its output is a plain copy
                 enc = chunk
             body += struct.pack("<i", len(enc)) + enc

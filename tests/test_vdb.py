@@ -65,6 +65,23 @@ def test_vdb_loader_matches_the_reference_semantics(tmp_path, kw):
     assert got.max() == 255
 
 
+def test_blosc_frames_with_lz4_streams_from_the_real_library(tmp_path, monkeypatch):
+    """The Blosc path again with the LZ4 streams produced by the system's liblz4 (the real encoder: long matches,
+    overlapping copies, its own parsing choices) instead of the test writer's: the product's LZ4 decoder must read what
+    the real library writes.  (liblz4.so.1 is on the image as a runtime library; no Blosc or OpenVDB library is.)"""
+    real = _vdb.system_lz4()
+    if real is None:
+        pytest.skip("liblz4.so.1 not found")
+    monkeypatch.setattr(_vdb, "LZ4_ENCODER", real[0])
+    v, a = _cloud((60, 41, 37), seed=13)
+    v[5:25, 5:25, 5:25] = 1.5                      # long runs: the real encoder emits long and overlapping matches
+    a = v > 0
+    for comp in (_vdb.COMPRESS_BLOSC, _vdb.COMPRESS_BLOSC | _vdb.COMPRESS_ACTIVE_MASK):
+        path = tmp_path / f"real{comp}.vdb"
+        _vdb.write_vdb(path, v, a, origin=(3, -70, 120), compression=comp)
+        assert np.array_equal(ds.load_vdb(path), _vdb.reference_texture(v, a, (3, -70, 120)))
+
+
 def test_vdb_half_float_grid_and_a_large_tile(tmp_path):
     v, a = _cloud((20, 24, 18), seed=3, leak=False)
     v = v.astype(np.float16).astype(np.float32)
@@ -157,6 +174,11 @@ def test_lz4_and_blosc_frames_of_the_test_writer_are_well_formed():
         enc = _vdb.lz4_encode(data)
         assert lz4_decode(enc, len(data)) == data
     assert len(_vdb.lz4_encode(bytes(4096))) < 64
+    real = _vdb.system_lz4()
+    if real is not None:                            # and against the real library, both ways
+        for data in (bytes(4096), bytes(rng.integers(0, 4, 5000, dtype=np.uint8)), b"abcd" * 300 + b"xyz"):
+            assert real[1](_vdb.lz4_encode(data), len(data)) == data
+            assert lz4_decode(real[0](data), len(data)) == data
 
 
 @pytest.mark.gpu

@@ -1590,6 +1590,8 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0;
     uint32_t iv_dealt = 0, iv_written = 0, iv_resumed = 0, iv_suspended = 0; // path conservation (STATS kernels)
+    uint32_t st_hist_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, st_hist_s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // visits by lanes taking part (bins of 8)
+    uint32_t st_drained_t = 0;                                                                          // tracking visits after the wave found the job list empty
 
     // ---------------- path continuation, as in render_persistent_kernel (kContWordsDelta words per path) ----------------
     bool resumed = false;
@@ -1741,6 +1743,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             if (STATS) {
                 st_scat += 1;
                 st_scat_l += nb;
+                st_hist_s[min((nb - 1u) >> 3, 7u)] += 1;
             }
             if (state == ST_BOUNCE) {
                 const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
@@ -1768,6 +1771,10 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             if (STATS) {
                 st_march += 1;
                 st_march_l += nm;
+                if (nm) {
+                    st_hist_t[min((nm - 1u) >> 3, 7u)] += 1;
+                }
+                st_drained_t += drained ? 1u : 0u;
             }
             uint32_t burst = drained ? sc.tail_burst : sc.march_burst;
             for (;;) {
@@ -1853,6 +1860,8 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             if (STATS) {
                 st_march += 1;
                 st_march_l += m_now;
+                st_hist_t[min((m_now - 1u) >> 3, 7u)] += 1;
+                st_drained_t += drained ? 1u : 0u;
             }
             }
         }
@@ -1937,6 +1946,11 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             atomicAdd(&ba.stats[6], (unsigned long long)sv[0]);
             atomicAdd(&ba.stats[7], (unsigned long long)sv[1]);
             atomicAdd(&ba.stats[8], (unsigned long long)sv[2]);
+            for (int i = 0; i < 8; i++) {
+                atomicAdd(&ba.stats[16 + i], (unsigned long long)st_hist_t[i]);
+                atomicAdd(&ba.stats[24 + i], (unsigned long long)st_hist_s[i]);
+            }
+            atomicAdd(&ba.stats[32], (unsigned long long)st_drained_t);
             atomicAdd(&ba.stats[64], (unsigned long long)sv[3]);
             atomicAdd(&ba.stats[65], (unsigned long long)sv[4]);
             atomicAdd(&ba.stats[66], (unsigned long long)sv[5]);

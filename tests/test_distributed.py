@@ -44,7 +44,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 8])
 def test_gloo_frame_reduce_rebuilds_the_whole_frame(tmp_path, world):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 2000)

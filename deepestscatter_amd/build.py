@@ -53,7 +53,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> Path:
             ROOT / "include" / "cloudtrace.h"]
     if not force and CLI.exists() and LIB.exists() and all(s.stat().st_mtime <= CLI.stat().st_mtime for s in srcs + [LIB]):
         return CLI
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-o", str(CLI), str(HOST / "main.cpp"), f"-L{PKG}", "-lcloudtrace",
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-o", str(CLI), str(HOST / "main.cpp"), f"-L{PKG}", "-lcloudtrace",
            "-Wl,-rpath,$ORIGIN/.."]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -105,6 +105,17 @@ struct CtHandle_ {
     bool debug_invariants = false;
     uint64_t iv_expected_dealt = 0, iv_checks = 0, iv_violations = 0;
 
+    // ct_point_radiance_launch: a collector calls it about a thousand times per scene setup, each call a launch of a few
+    // milliseconds, so its device buffers stay (grown on demand; freeing one would wait for the whole device, i.e. for
+    // the launches of the other scene setups in flight)
+    struct PointBuffers {
+        CtPointRadianceTask *tasks = nullptr;
+        float4 *primary = nullptr, *frames = nullptr;
+        uint32_t *pixels = nullptr, *jg = nullptr, *js = nullptr;
+        size_t cap_tasks = 0, cap_primary = 0, cap_pixels = 0, cap_frames = 0, cap_jg = 0, cap_js = 0;
+    } pt;
+    bool point_order = true;             // CT_POINT_ORDER=0: jobs of 8 frames in task order over 8 queues, as until round 2 (A/B)
+
     size_t volume_bytes = 0;
     LaunchShape shape{ 1024, 256, false };
     uint32_t subframes = 0;
@@ -252,7 +263,7 @@ static void release(CtHandle h)
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->slots[0].queue, h->slots[1].queue, h->slots[0].cont, h->slots[1].cont, h->d_cont_count, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
-                     h->d_counters, h->d_colsum, h->d_avg };
+                     h->d_counters, h->d_colsum, h->d_avg, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
         if (p) {
             hipFree(p);
@@ -461,6 +472,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     d.nee_cache = (bgx * bgy * bgz < (1ll << 25)) ? 1u : 0u;
     if (const char *e = getenv("CT_NEE_CACHE")) {
         d.nee_cache = (atoi(e) != 0 && d.nee_cache) ? 1u : 0u;
+    }
+    if (const char *e = getenv("CT_POINT_ORDER")) {
+        h->point_order = atoi(e) != 0;
     }
     d.brick_gx = (int32_t)bgx;
     d.brick_gxy = (int32_t)(bgx * bgy);
@@ -1518,50 +1532,84 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
     if ((uint64_t)n_pad * launches > 0xffffffffull) {
         return fail(h, CT_E_INVAL, "too many task-launches for one call");
     }
-    // job list: every group of 64 tasks, `launches` frames in jobs of up to 8
+    // ---- job list.  A job = (group of 64 tasks, range of frames).  A collector's call is small -- 20480 tasks x 100
+    // frames are 32000 wave-jobs of 64 experiments for the chip's 6144 resident waves -- and most of its work is in the few
+    // tasks deep inside the cloud, whose every experiment runs to the depth cap (2000 bounces): jobs are single frames
+    // unless the call is large, in one queue, frame-major, so that the deep groups are spread evenly over the list and over
+    // the waves.  (What bounds such a call is the serial latency of those paths, ~6 us per bounce: DESIGN.md section 8 f-1.)
+    const uint32_t waves = (uint32_t)h->shape.blocks * (uint32_t)h->shape.threads / 64u;
+    const uint32_t chunk = h->point_order
+                               ? (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (uint64_t)n_groups * launches / (16ull * std::max(waves, 1u))))
+                               : 8u;
     std::vector<uint32_t> jg, js;
-    for (uint32_t g = 0; g < n_groups; g++) {
-        for (uint32_t s0 = 0; s0 < launches; s0 += 8) {
-            jg.push_back(g);
-            js.push_back(s0 | (std::min(8u, launches - s0) << 16));
-        }
-    }
-    void *d_tasks = nullptr;
-    float4 *d_primary = nullptr, *d_frames = nullptr;
-    uint32_t *d_pixels = nullptr, *d_jg = nullptr, *d_js = nullptr, *d_cost = nullptr;
-    auto cleanup = [&]() {
-        for (void *p : { d_tasks, (void *)d_primary, (void *)d_frames, (void *)d_pixels, (void *)d_jg, (void *)d_js,
-                         (void *)d_cost }) {
-            if (p) {
-                hipFree(p);
+    jg.reserve((size_t)n_groups * ((launches + chunk - 1) / chunk));
+    js.reserve(jg.capacity());
+    if (h->point_order) {
+        for (uint32_t s0 = 0; s0 < launches; s0 += chunk) {
+            for (uint32_t g = 0; g < n_groups; g++) {
+                jg.push_back(g);
+                js.push_back(s0 | (std::min(chunk, launches - s0) << 16));
             }
         }
-    };
+    } else {
+        for (uint32_t g = 0; g < n_groups; g++) {
+            for (uint32_t s0 = 0; s0 < launches; s0 += chunk) {
+                jg.push_back(g);
+                js.push_back(s0 | (std::min(chunk, launches - s0) << 16));
+            }
+        }
+    }
+    CtHandle_::PointBuffers &pt = h->pt;
     auto run = [&]() -> int {
-        HIPCHK(h, hipMalloc(&d_tasks, (size_t)count * sizeof(CtPointRadianceTask)));
-        HIPCHK(h, dmalloc(&d_primary, 2 * (size_t)n_pad));
-        HIPCHK(h, dmalloc(&d_frames, (size_t)n_pad * launches));
-        HIPCHK(h, dmalloc(&d_pixels, n_pad));
-        HIPCHK(h, dmalloc(&d_jg, jg.size()));
-        HIPCHK(h, dmalloc(&d_js, js.size()));
-        HIPCHK(h, dmalloc(&d_cost, n_groups));
-        HIPCHK(h, hipMemcpyAsync(d_tasks, tasks_host, (size_t)count * sizeof(CtPointRadianceTask),
+        // (re)allocation waits for the device, so it happens only when a call is larger than every call before it
+        const auto grow = [&](auto **p, size_t &cap, size_t need) -> hipError_t {
+            if (need <= cap) {
+                return hipSuccess;
+            }
+            if (*p) {
+                hipError_t e = hipFree(*p);
+                *p = nullptr;
+                cap = 0;
+                if (e != hipSuccess) {
+                    return e;
+                }
+            }
+            hipError_t e = hipMalloc((void **)p, need * sizeof(**p));
+            if (e == hipSuccess) {
+                cap = need;
+            }
+            return e;
+        };
+        HIPCHK(h, grow(&pt.tasks, pt.cap_tasks, count));
+        HIPCHK(h, grow(&pt.primary, pt.cap_primary, 2 * (size_t)n_pad));
+        HIPCHK(h, grow(&pt.pixels, pt.cap_pixels, n_pad));
+        HIPCHK(h, grow(&pt.frames, pt.cap_frames, (size_t)n_pad * launches));
+        HIPCHK(h, grow(&pt.jg, pt.cap_jg, jg.size()));
+        HIPCHK(h, grow(&pt.js, pt.cap_js, js.size()));
+        HIPCHK(h, hipMemcpyAsync(pt.tasks, tasks_host, (size_t)count * sizeof(CtPointRadianceTask),
                                  hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(d_jg, jg.data(), jg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(d_js, js.data(), js.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemsetAsync(d_cost, 0, n_groups * sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemcpyAsync(pt.jg, jg.data(), jg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(pt.js, js.data(), js.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
-        HIPCHK(h, launch_point_rays(h->dev, d_tasks, count, n_pad, d_primary, d_pixels, h->stream));
+        HIPCHK(h, launch_point_rays(h->dev, pt.tasks, count, n_pad, pt.primary, pt.pixels, h->stream));
         BatchArgs ba{};
-        ba.frames = d_frames;
+        ba.frames = pt.frames;
         ba.frame_stride = n_pad;
-        ba.primary = d_primary;
-        ba.pixels = d_pixels;
-        ba.job_group = d_jg;
-        ba.job_sub = d_js;
+        ba.primary = pt.primary;
+        ba.pixels = pt.pixels;
+        ba.job_group = pt.jg;
+        ba.job_sub = pt.js;
         ba.cost = nullptr;
         ba.n_jobs = (uint32_t)jg.size();
-        split_queues_evenly(ba);
+        if (h->point_order) {
+            // one queue: the order above is the order the chip's waves take the jobs in
+            ba.q_begin[0] = 0;
+            for (int x = 1; x <= kQueues + 1; x++) {
+                ba.q_begin[x] = ba.n_jobs;
+            }
+        } else {
+            split_queues_evenly(ba);
+        }
         ba.first_subframe = first_frame_id;
         ba.S = launches;
         ba.queue = h->d_queue;
@@ -1574,8 +1622,8 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
             HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
         }
         HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-        HIPCHK(h, launch_point_accumulate(d_frames, n_pad, d_tasks, count, launches, h->stream));
-        HIPCHK(h, hipMemcpyAsync(tasks_host, d_tasks, (size_t)count * sizeof(CtPointRadianceTask),
+        HIPCHK(h, launch_point_accumulate(pt.frames, n_pad, pt.tasks, count, launches, h->stream));
+        HIPCHK(h, hipMemcpyAsync(tasks_host, pt.tasks, (size_t)count * sizeof(CtPointRadianceTask),
                                  hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         float ms = 0;
@@ -1584,13 +1632,18 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         h->launches += 1;
         h->host_paths += (unsigned long long)count * launches;
         h->iv_expected_dealt += (unsigned long long)count * launches;
+        if (pt.cap_frames > ((size_t)64 << 20)) {
+            // an unusually large call (> 1 GiB of per-experiment results): do not keep that much for the handle's life
+            HIPCHK(h, hipFree(pt.frames));
+            pt.frames = nullptr;
+            pt.cap_frames = 0;
+        }
         return CT_OK;
     };
     const int rc = run();
     if (rc != CT_OK) {
         hipStreamSynchronize(h->stream);
     }
-    cleanup();
     return rc;
 }
 

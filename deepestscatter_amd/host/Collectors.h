@@ -14,6 +14,7 @@
 // compare the two.
 #pragma once
 
+#include <chrono>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -112,6 +113,18 @@ namespace DeepestScatter
         }
     }
 
+    // The collectors log like the reference's (std::cout); with several scene setups in flight (`cloudtrace collect --jobs`)
+    // the per-update lines of different scenes would interleave, so they can be switched off.
+    struct CollectorLog
+    {
+        static bool& quiet() { static bool q = false; return q; }
+        static std::ostream& out()
+        {
+            static std::ostream null(nullptr);                                    // no buffer: every write is dropped
+            return quiet() ? null : std::cout;
+        }
+    };
+
     // Dataset (Dataset.h:20-110): one named table per message type, int32 record ids.  batchAppend / getRecord like the
     // reference; `save` writes the flat stand-in for the LMDB environment (see the header comment).
     class Dataset
@@ -127,6 +140,11 @@ namespace DeepestScatter
             const auto t = tables.find(table);
             if (t == tables.end() || !t->second.count(id)) throw std::runtime_error("no record " + std::to_string(id) + " in table " + table);
             return t->second.at(id);
+        }
+        void merge(const Dataset& other)                                                                          // the tables of another scene setup (disjoint record ids)
+        {
+            for (const auto& [name, records] : other.tables)
+                for (const auto& [id, bytes] : records) tables[name][id] = bytes;
         }
         size_t getRecordsCount(const std::string& table) const { const auto t = tables.find(table); return t == tables.end() ? 0 : t->second.size(); }
 
@@ -179,18 +197,18 @@ namespace DeepestScatter
         void update() override                                                  // reset() + collect(), :22-62
         {
             if (done) return;
-            std::cout << "Generating samples..." << std::endl;
+            CollectorLog::out() << "Generating samples..." << std::endl;
             std::vector<float> positions(3 * (size_t)settings.batchSize), directions(3 * (size_t)settings.batchSize);
             // one launch over batchSize threads; the batch's first record id seeds it (the reference mixes in clock())
             Context::check(ct_generate_scatter_samples(context->handle, settings.batchSize, settings.batchStartId, positions.data(), directions.data()),
                            context->handle, "ct_generate_scatter_samples");
-            std::cout << "Serializing samples..." << std::endl;
+            CollectorLog::out() << "Serializing samples..." << std::endl;
             std::vector<std::string> samples(settings.batchSize);
             for (uint32_t i = 0; i < settings.batchSize; i++)
                 samples[i] = Persistance::scatterSample(sceneSetupId, &positions[3 * (size_t)i], &directions[3 * (size_t)i]);
-            std::cout << "Writing samples..." << std::endl;
+            CollectorLog::out() << "Writing samples..." << std::endl;
             dataset->batchAppend("ScatterSample", samples, (int32_t)settings.batchStartId);
-            std::cout << "Finished writing samples." << std::endl;
+            CollectorLog::out() << "Finished writing samples." << std::endl;
             done = true;
         }
         bool isCompleted() override { return done; }
@@ -232,10 +250,15 @@ namespace DeepestScatter
         {
             if (allPixelsConverged) return;
             // 100 launches of estimateEmission over the replicated tasks, frame ids frameId+1 .. frameId+100 (:84-96)
+            const auto t1 = std::chrono::steady_clock::now();
             Context::check(ct_point_radiance_launch(context->handle, tasksBuffer.data(), threadsCount, frameId + 1, 100), context->handle,
                            "ct_point_radiance_launch");
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
             frameId += 100;
-            std::cout << "MS/Render: - " << settings.batchSize - (uint32_t)getConvergedCount() << std::endl;
+            totalRenderMs += ms;
+            totalExperiments += (uint64_t)threadsCount * 100u;
+            updates++;
+            CollectorLog::out() << "MS/Render: " << ms << " " << settings.batchSize - (uint32_t)getConvergedCount() << std::endl;   // :97
             std::vector<CtPointRadianceTask> todoTasks;
             const uint32_t remaining = (uint32_t)getRemainingCount();
             for (uint32_t i = 0; i < remaining; i++)
@@ -247,12 +270,17 @@ namespace DeepestScatter
                 (isConverged ? convergedTasks : todoTasks).push_back(representative);
             }
             allPixelsConverged = getConvergedCount() == (int32_t)settings.batchSize;
-            std::cout << "converged: " << getConvergedCount() << " of " << settings.batchSize << std::endl;
+            CollectorLog::out() << "converged: " << getConvergedCount() << " of " << settings.batchSize << std::endl;
             if (allPixelsConverged) recordToDataset();
             else scheduleTasks(todoTasks);
         }
 
         bool isCompleted() override { return allPixelsConverged; }
+
+        // what the reference's "MS/Render" lines add up to (RadianceCollector.cpp:87-97), for `cloudtrace collect --timings`
+        double totalRenderMs = 0;
+        uint64_t totalExperiments = 0;
+        uint32_t updates = 0;
 
         // PointRadianceTask.h:23-36 (95 % confidence), :56-68 (operator+=: the M2 values are added as they are)
         static float absoluteConfidenceInterval(const CtPointRadianceTask& t)
@@ -275,12 +303,12 @@ namespace DeepestScatter
         void recordToDataset()                                                   // :148-169
         {
             std::sort(convergedTasks.begin(), convergedTasks.end(), [](const CtPointRadianceTask& a, const CtPointRadianceTask& b) { return a.id < b.id; });
-            std::cout << "Serializing emissions..." << std::endl;
+            CollectorLog::out() << "Serializing emissions..." << std::endl;
             std::vector<std::string> results(settings.batchSize);
             for (uint32_t i = 0; i < settings.batchSize; i++) results[i] = Persistance::result(convergedTasks[i].radiance, true);
-            std::cout << "Writing emissions..." << std::endl;
+            CollectorLog::out() << "Writing emissions..." << std::endl;
             dataset->batchAppend("Result", results, (int32_t)settings.batchStartId);
-            std::cout << "Finished writing emissions." << std::endl;
+            CollectorLog::out() << "Finished writing emissions." << std::endl;
         }
 
         void scheduleTasks(const std::vector<CtPointRadianceTask>& tasks)        // :176-192

@@ -130,6 +130,44 @@ def test_point_radiance_launch_bit_exact_on_gpu():
 
 
 @pytest.mark.gpu
+def test_point_radiance_job_order_never_changes_a_result(monkeypatch):
+    """ct_point_radiance_launch keeps its device buffers between calls and cuts a small call into single-frame jobs, handed
+    out frame-major from one queue.  None of that may show in a result: calls of growing and shrinking size, re-packed task
+    lists whose ids come back at other positions, against the oracle and against a handle with the round-1 job list
+    (CT_POINT_ORDER=0: jobs of 8 frames in task order over 8 queues)."""
+    tex = sphere_volume(32, seed=21)
+    pos, d = sample_tasks(300, seed=17)
+    orc = O.Oracle(tex, 8, 8, mode=1, fast=True)
+    monkeypatch.setenv("CT_POINT_ORDER", "0")
+    plain = ds.CloudTracer(tex, width=8, height=8, mode=1)
+    monkeypatch.delenv("CT_POINT_ORDER")
+    tr = ds.CloudTracer(tex, width=8, height=8, mode=1)
+    rng = np.random.default_rng(3)
+    tasks = ds.make_point_tasks(pos, d)
+    frame = 1
+    for step, (count, launches) in enumerate([(300, 3), (300, 20), (70, 9), (300, 2), (129, 33)]):
+        if step == 2:
+            # what a collector does between updates: the unconverged tasks, re-packed with replicas (ids repeat, move)
+            keep = np.sort(rng.choice(300, 7, replace=False))
+            tasks = np.repeat(tasks[keep], 10)
+        elif step == 3:
+            tasks = ds.make_point_tasks(pos[::-1].copy(), d[::-1].copy())            # every id now names another task
+        elif step == 4:
+            tasks = tasks[:129].copy()
+        assert len(tasks) == count
+        got = tr.point_radiance_launch(tasks.copy(), frame, launches)
+        ref = orc.point_radiance_launch(tasks.copy(), frame, launches)
+        old = plain.point_radiance_launch(tasks.copy(), frame, launches)
+        assert got.tobytes() == ref.tobytes(), step
+        assert old.tobytes() == ref.tobytes(), step
+        tasks = got
+        frame += launches
+    assert tr.counters() == plain.counters()
+    tr.close()
+    plain.close()
+
+
+@pytest.mark.gpu
 def test_collector_end_to_end_on_gpu(tmp_path):
     tex = sphere_volume(32, seed=12)
     tr = ds.CloudTracer(tex, width=8, height=8, mode=1)             # SunMultipleScatter, Tasks.cpp:135
@@ -314,3 +352,36 @@ def test_cpp_cli_collect_equals_the_python_pipeline(tmp_path):
     table, setup = col.read_flat_dataset(out / "SceneSetup.flat")
     assert table == "SceneSetup" and len(setup) == 1 and setup[0][0] == scene_id and b"procedural:48" in setup[0][1]
     tr.close()
+
+
+@pytest.mark.gpu
+def test_cpp_cli_collect_with_scene_setups_in_flight_writes_the_same_tables(tmp_path):
+    """`cloudtrace collect @list --jobs 3`: three scene setups (different clouds, lights, sizes) collected by three host threads
+    with a renderer handle each, their launches overlapping on the device, write the union of the tables that three runs
+    of one setup each write -- byte for byte, whatever the threads' order."""
+    import subprocess
+    from deepestscatter_amd import build
+    cli = build.build_cli()
+    rows = [("procedural:40:7", "Side", 7000.0), ("procedural:48", "Back", 5000.0), ("procedural:40:9", "-0.3,-0.8,0.2", 7000.0)]
+    batch, first = 64, 5
+    lst = tmp_path / "setups.txt"
+    lst.write_text("# cloud light size\n" + "".join(f"{c} {l} {m}\n" for c, l, m in rows))
+    out = tmp_path / "all"
+    r = subprocess.run([str(cli), "collect", f"@{lst}", "--batch", str(batch), "--scene-id", str(first), "--jobs", "3", "--out", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("collect_timings") == 3 and '"jobs": 3' in r.stdout
+    merged = {}
+    for i, (c, l, m) in enumerate(rows):
+        one = tmp_path / f"one{i}"
+        single = tmp_path / f"setup{i}.txt"
+        single.write_text(f"{c} {l} {m}\n")
+        r1 = subprocess.run([str(cli), "collect", f"@{single}", "--batch", str(batch), "--scene-id", str(first + i), "--out", str(one)],
+                            capture_output=True, text=True, timeout=900)
+        assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+        for table in ("SceneSetup", "ScatterSample", "Result", "DisneyDescriptor"):
+            name, recs = col.read_flat_dataset(one / f"{table}.flat")
+            merged.setdefault(name, []).extend(recs)
+    for table, recs in merged.items():
+        assert col.read_flat_dataset(out / f"{table}.flat") == (table, sorted(recs)), table
+    assert len(merged["Result"]) == 3 * batch and len(merged["SceneSetup"]) == 3

@@ -1,3 +1,8 @@
+"""How many estimator kernels were resident at once: reads the kernel trace (CSV) under a rocprofv3 output directory.
+
+    rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 tools/point_concurrency_probe.py 4
+    python tools/kernel_overlap.py OUT
+"""
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "render_" in r["Kernel_Name"]]

@@ -1,7 +1,14 @@
+"""K renderer handles on one GPU, one host thread each, every thread calling ct_point_radiance_launch the way a
+RadianceCollector does (20480 threads x 100 frames, 20 calls): aggregate ms per update and experiments/s.
+
+    python tools/point_concurrency_probe.py K [estimator=0]
+
+Under `rocprofv3 --kernel-trace` its trace feeds tools/kernel_overlap.py (how many estimator kernels are resident at once).
+"""
 import sys, time, threading
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import deepestscatter_amd as ds
 K = int(sys.argv[1]); est = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 tex = ds.make_procedural_cloud(256)

@@ -93,20 +93,33 @@ class RadianceCollector:
             return
         self.launch(self.tasks_buffer, self.frame_id + 1, self.launches_per_update)   # :88-96
         self.frame_id += self.launches_per_update
-        todo = []
         r = self.task_repeat_count
-        for i in range(self.get_remaining_count()):
-            rep = self.tasks_buffer[i * r].copy()
-            for j in range(1, r):
-                merge_tasks(rep, self.tasks_buffer[i * r + j])
-            converged = bool(relative_confidence_interval(rep["radiance"], rep["runningVariance"], rep["experimentCount"]) < f32(2e-2)
-                             or absolute_confidence_interval(rep["radiance"], rep["runningVariance"], rep["experimentCount"]) < f32(1e-4))
-            if rep["radiance"] < FLT_EPSILON:
-                converged = int(rep["experimentCount"]) > 100000
-            (self.converged_tasks if converged else todo).append(rep)
+        n = self.get_remaining_count()
+        # representative += replica j, j = 1 .. r-1 (:104-108): the reference's scalar float32 operations in its order,
+        # carried out for all remaining tasks at once (merge_tasks is the same arithmetic for one pair)
+        buf = self.tasks_buffer[:n * r].reshape(n, r)
+        rep = buf[:, 0].copy()
+        rad, var, cnt = rep["radiance"].astype(f32), rep["runningVariance"].astype(f32), rep["experimentCount"].astype(np.int64)
+        for j in range(1, r):
+            o = buf[:, j]
+            if np.any(o["id"] != rep["id"]):
+                raise ValueError("Different point radiance tasks cannot be merged into one!")
+            n1 = o["experimentCount"].astype(np.int64)
+            new_weight = (n1.astype(f32) * f32(1.0)) / (cnt + n1).astype(f32)
+            rad = rad + (o["radiance"] - rad) * new_weight
+            var = var + o["runningVariance"]
+            cnt = cnt + n1
+        rep["radiance"], rep["runningVariance"], rep["experimentCount"] = rad, var, cnt
+        with np.errstate(divide="ignore", invalid="ignore"):
+            N = cnt.astype(f32)
+            absolute = (f32(1.96) * np.sqrt(var / N)) / np.sqrt(N)                    # PointRadianceTask.h:31-36
+            relative = absolute / (rad + FLT_EPSILON)                                 # :23-26
+        converged = (relative < f32(2e-2)) | (absolute < f32(1e-4))                   # :112-114
+        converged = np.where(rad < FLT_EPSILON, cnt > 100000, converged)              # :115-118
+        self.converged_tasks.extend(rep[converged])
         self.all_pixels_converged = self.get_converged_count() == self.batch_size
         if not self.all_pixels_converged:
-            self._schedule(np.array(todo, POINT_TASK_DTYPE))
+            self._schedule(rep[~converged])
 
     # recordToDataset(), :148-169
     def results(self) -> list[tuple[int, bytes]]:

@@ -385,3 +385,44 @@ def test_cpp_cli_collect_with_scene_setups_in_flight_writes_the_same_tables(tmp_
     for table, recs in merged.items():
         assert col.read_flat_dataset(out / f"{table}.flat") == (table, sorted(recs)), table
     assert len(merged["Result"]) == 3 * batch and len(merged["SceneSetup"]) == 3
+
+
+def test_vectorised_update_equals_the_scalar_merge():
+    """RadianceCollector.update merges the replicas of all tasks at once; the result must be what the reference's loop
+    gives task by task (merge_tasks = PointRadianceTask::operator+=, the two confidence intervals, the zero-radiance rule)."""
+    rng = np.random.default_rng(11)
+
+    def fake_launch(buf, first_frame, launches):
+        # any statistics will do: random radiance, variance and counts, a few all-zero tasks
+        buf["radiance"] = rng.random(len(buf), dtype=np.float32) * rng.choice([0.0, 1e-3, 1.0], len(buf)).astype(np.float32)
+        buf["runningVariance"] = rng.random(len(buf), dtype=np.float32) * 5
+        buf["experimentCount"] = rng.integers(1, 300000, len(buf))
+        return buf
+
+    pos, d = sample_tasks(37, seed=2)
+    c = col.RadianceCollector(fake_launch, pos, d, max_thread_count=37 * 6 + 5, launches_per_update=10)
+    for _ in range(4):
+        if c.is_completed():
+            break
+        r, n = c.task_repeat_count, c.get_remaining_count()
+        before = len(c.converged_tasks)
+        fake_launch(c.tasks_buffer, 0, 0)
+        snapshot = c.tasks_buffer.copy()
+        c.launch = lambda buf, a, b: buf                           # update() sees exactly `snapshot`
+        c.update()
+        c.launch = fake_launch
+        want_conv, want_todo = [], []
+        for i in range(n):
+            rep = snapshot[i * r].copy()
+            for j in range(1, r):
+                col.merge_tasks(rep, snapshot[i * r + j])
+            conv = bool(col.relative_confidence_interval(rep["radiance"], rep["runningVariance"], rep["experimentCount"]) < np.float32(2e-2)
+                        or col.absolute_confidence_interval(rep["radiance"], rep["runningVariance"], rep["experimentCount"]) < np.float32(1e-4))
+            if rep["radiance"] < col.FLT_EPSILON:
+                conv = int(rep["experimentCount"]) > 100000
+            (want_conv if conv else want_todo).append(rep)
+        got_conv = c.converged_tasks[before:]
+        assert [t.tobytes() for t in got_conv] == [t.tobytes() for t in want_conv]
+        if want_todo:
+            r2 = c.task_repeat_count
+            assert [c.tasks_buffer[i * r2].tobytes() for i in range(len(want_todo))] == [t.tobytes() for t in want_todo]

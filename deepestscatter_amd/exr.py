@@ -1,5 +1,5 @@
 """Minimal OpenEXR 2 reader/writer for the one layout the path uses (Camera::saveToDisk, Camera.cpp:149-175):
-single part, scan lines, FLOAT channels B, G, R, uncompressed, any line order.  OpenEXR is not installed on
+single part, scan lines, FLOAT channels B, G, R, uncompressed, any line order (the reader also takes HALF channels).  OpenEXR is not installed on
 the target image; the C++ host writes the same bytes (host/Exr.h)."""
 from __future__ import annotations
 
@@ -45,8 +45,10 @@ def write_exr(path, rgb: np.ndarray, decreasing_y: bool = True) -> None:
             f.write(np.ascontiguousarray(rgb[y, :, ::-1].T).tobytes())   # B, G, R planes
 
 
-def read_exr(path) -> np.ndarray:
-    """-> float32 [H, W, 3] (R, G, B).  Only what write_exr / host/Exr.h produce."""
+def read_exr(path, with_info: bool = False):
+    """-> float32 [H, W, 3] (R, G, B); with_info: also {"channels": [(name, "HALF" | "FLOAT")], "line_order": 0 | 1}.
+    Single-part scan-line files without compression with HALF or FLOAT channels: what write_exr / host/Exr.h produce,
+    and enough of the format to read such a file written by the OpenEXR library itself (tests/golden/)."""
     b = open(path, "rb").read()
     if b[:4] != MAGIC or struct.unpack_from("<i", b, 4)[0] != 2:
         raise ValueError("not a single-part OpenEXR 2 file")
@@ -65,23 +67,30 @@ def read_exr(path) -> np.ndarray:
         raise ValueError("only uncompressed files")
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     w, h = x1 - x0 + 1, y1 - y0 + 1
-    names, c = [], attrs["channels"][1]
+    channels, c = [], attrs["channels"][1]
     p = 0
     while c[p] != 0:
         q = c.index(b"\0", p)
-        names.append(c[p:q].decode())
-        if struct.unpack_from("<i", c, q + 1)[0] != 2:
-            raise ValueError("only FLOAT channels")
+        pixel_type, _, xs, ys = struct.unpack_from("<iB3xii", c, q + 1)
+        if pixel_type not in (1, 2) or (xs, ys) != (1, 1):
+            raise ValueError("only HALF / FLOAT channels without subsampling")
+        channels.append((c[p:q].decode(), pixel_type))
         p = q + 1 + 16
+    row_bytes = sum(w * (2 if t == 1 else 4) for _, t in channels)
     table = struct.unpack_from(f"<{h}Q", b, i)
-    out = np.empty((h, w, 3), np.float32)
+    out = np.zeros((h, w, 3), np.float32)
     for y in range(h):
         off = table[y]
         yy, size = struct.unpack_from("<ii", b, off)
-        if yy != y0 + y or size != len(names) * w * 4:
+        if yy != y0 + y or size != row_bytes:
             raise ValueError("corrupt scan line")
-        planes = np.frombuffer(b, np.float32, len(names) * w, off + 8).reshape(len(names), w)
-        for ci, name in enumerate(names):
-            if name in "RGB":
-                out[y, :, "RGB".index(name)] = planes[ci]
+        off += 8
+        for name, t in channels:                       # one plane per channel, in the channel list's (alphabetical) order
+            plane = np.frombuffer(b, np.float16 if t == 1 else np.float32, w, off)
+            off += plane.nbytes
+            if name in ("R", "G", "B"):
+                out[y, :, "RGB".index(name)] = plane
+    if with_info:
+        return out, {"channels": [(n, "HALF" if t == 1 else "FLOAT") for n, t in channels], "line_order": attrs["lineOrder"][1][0],
+                     "attributes": sorted(attrs)}
     return out

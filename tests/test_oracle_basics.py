@@ -5,6 +5,7 @@ known answers that follow from the reference's formulas, independent numpy resta
 from the same reference lines, and the goldens of SURVEY.md section 8(c).
 """
 import ctypes as C
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -351,6 +352,38 @@ def test_exr_writer_reader_round_trip(tmp_path):
         assert np.array_equal(exr.read_exr(p), img)
     # size = header + offset table + height * (8 + 3 * width * 4)
     assert len(raw) - raw.index(b"screenWindowWidth") < 40 + 8 * 9 + 9 * (8 + 3 * 13 * 4)
+
+
+def test_exr_reader_reads_a_file_written_by_the_openexr_library():
+    """The container the writer emits (magic, version word, attribute encoding, offset table, one chunk per scan line with
+    y, byte count and one plane per channel in channel-list order) is the one a real OpenEXR file has:
+    tests/golden/cpython_imghdrdata_python.exr is CPython's Lib/test/imghdrdata/python.exr, a 16x16 uncompressed RGBA
+    HALF image written by the OpenEXR library.  The reader that round-trips write_exr's files parses it with every
+    consistency check on (chunk y, chunk size, table offsets); and a copy of its pixels written by write_exr reads back equal."""
+    from deepestscatter_amd import exr
+    src = Path(__file__).parent / "golden" / "cpython_imghdrdata_python.exr"
+    img, info = exr.read_exr(src, with_info=True)
+    assert img.shape == (16, 16, 3) and np.isfinite(img).all() and img.min() >= 0 and 0 < img.max() <= 1.5
+    assert info["channels"] == [("A", "HALF"), ("B", "HALF"), ("G", "HALF"), ("R", "HALF")] and info["line_order"] == 0
+    # the eight attributes of that file are exactly the eight the writer emits
+    assert info["attributes"] == ["channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio",
+                                  "screenWindowCenter", "screenWindowWidth"]
+    raw = src.read_bytes()
+    assert len(raw) == raw.index(b"screenWindowWidth") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1 + 8 * 16 + 16 * (8 + 4 * 16 * 2)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        exr.write_exr(Path(d) / "copy.exr", img, decreasing_y=False)
+        again, info2 = exr.read_exr(Path(d) / "copy.exr", with_info=True)
+        assert np.array_equal(again, img) and info2["attributes"] == info["attributes"]
+        # same header bytes up to the channel list's types: both start with magic, version 2 and the `channels` attribute
+        mine = (Path(d) / "copy.exr").read_bytes()
+        assert mine[:24] == raw[:24] == b"\x76\x2f\x31\x01\x02\0\0\0channels\0chlist\0"
+        # attributes whose value does not depend on the image (here: same size, same line order) are the same bytes in both
+        for name, typ, size in ((b"compression", b"compression", 1), (b"dataWindow", b"box2i", 16), (b"displayWindow", b"box2i", 16),
+                                (b"lineOrder", b"lineOrder", 1), (b"pixelAspectRatio", b"float", 4), (b"screenWindowCenter", b"v2f", 8),
+                                (b"screenWindowWidth", b"float", 4)):
+            k = mine.index(name + b"\0" + typ + b"\0")
+            assert mine[k:k + len(name) + len(typ) + 2 + 4 + size] in raw, name
 
 
 def test_delta_lower_bound_codes_only_skip_lookups():

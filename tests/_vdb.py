@@ -101,6 +101,41 @@ def system_lz4():
 LZ4_ENCODER = None   # set to system_lz4()[0] to have blosc_encode use the real library's streams
 
 
+def system_blosc():
+    """The real Blosc 1.x library where one is installed (a conda environment on the image has libblosc.so.1), called
+    the way OpenVDB's bloscToStream calls it (io/Compression.cc: clevel 9, shuffle, typesize sizeof(float), LZ4, one
+    block, one thread).  -> compress(bytes) -> frame, or None."""
+    import ctypes as C
+    import ctypes.util
+    lib = None
+    for cand in (ctypes.util.find_library("blosc"), "libblosc.so.1", "/opt/conda/lib/libblosc.so.1", "/usr/lib/x86_64-linux-gnu/libblosc.so.1"):
+        if not cand:
+            continue
+        try:
+            lib = C.CDLL(cand)
+            break
+        except OSError:
+            continue
+    if lib is None:
+        return None
+    lib.blosc_compress_ctx.restype = C.c_int
+    lib.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+    lib.blosc_get_version_string.restype = C.c_char_p
+
+    def compress(data: bytes) -> bytes:
+        cap = len(data) + 16                                    # BLOSC_MAX_OVERHEAD
+        out = C.create_string_buffer(cap)
+        n = lib.blosc_compress_ctx(9, 1, 4, len(data), data, out, cap, b"lz4", len(data), 1)
+        assert n > 0, n
+        return out.raw[:n]
+
+    compress.version = lib.blosc_get_version_string().decode()
+    return compress
+
+
+BLOSC_ENCODER = None   # set to system_blosc() to have the writer's Blosc frames made by the real library
+
+
 # ---- Blosc 1.x frame with the LZ4 codec and byte shuffle (what OpenVDB's bloscToStream asks Blosc for) -------------
 def blosc_encode(data: bytes, typesize: int = 4, blocksize: int = 0, memcpy: bool = False, shuffle: bool = True) -> bytes:
     n = len(data)
@@ -160,7 +195,7 @@ class _Writer:
         if self.c & COMPRESS_BLOSC:
             if len(raw) <= 48:                                       # bloscToStream: too small to bother
                 return struct.pack("<q", -len(raw)) + raw
-            frame = blosc_encode(raw, typesize=2 if self.half else 4, memcpy=self.blosc_memcpy)
+            frame = BLOSC_ENCODER(raw) if BLOSC_ENCODER else blosc_encode(raw, typesize=2 if self.half else 4, memcpy=self.blosc_memcpy)
             return struct.pack("<q", len(frame)) + frame
         if self.c & COMPRESS_ZIP:
             z = zlib.compress(raw)

@@ -68,7 +68,7 @@ def test_vdb_loader_matches_the_reference_semantics(tmp_path, kw):
 def test_blosc_frames_with_lz4_streams_from_the_real_library(tmp_path, monkeypatch):
     """The Blosc path again with the LZ4 streams produced by the system's liblz4 (the real encoder: long matches,
     overlapping copies, its own parsing choices) instead of the test writer's: the product's LZ4 decoder must read what
-    the real library writes.  (liblz4.so.1 is on the image as a runtime library; no Blosc or OpenVDB library is.)"""
+    the real library writes.  (liblz4.so.1 is on the image as a runtime library; whole frames from the real Blosc library: the next test.)"""
     real = _vdb.system_lz4()
     if real is None:
         pytest.skip("liblz4.so.1 not found")
@@ -80,6 +80,28 @@ def test_blosc_frames_with_lz4_streams_from_the_real_library(tmp_path, monkeypat
         path = tmp_path / f"real{comp}.vdb"
         _vdb.write_vdb(path, v, a, origin=(3, -70, 120), compression=comp)
         assert np.array_equal(ds.load_vdb(path), _vdb.reference_texture(v, a, (3, -70, 120)))
+
+
+def test_blosc_frames_from_the_real_blosc_library(tmp_path, monkeypatch):
+    """Every Blosc frame of the file made by the real Blosc library (1.21 in a conda environment of the image), called
+    with OpenVDB's own arguments (bloscToStream: clevel 9, shuffle, typesize 4, LZ4, one block): its header flags, its
+    split streams, its choice between compressed and stored blocks.  Smooth, noisy and constant leaf contents, float and
+    half grids, with and without active-mask compression."""
+    real = _vdb.system_blosc()
+    if real is None:
+        pytest.skip("no Blosc library on this machine")
+    monkeypatch.setattr(_vdb, "BLOSC_ENCODER", real)
+    rng = np.random.default_rng(23)
+    v, a = _cloud((70, 45, 52), seed=31)
+    v[8:40, 8:40, 8:40] = 0.75                                       # whole leaves of one value
+    v[40:60, 10:30, 10:40] = rng.random((20, 20, 30), dtype=np.float32) + 0.01   # incompressible mantissas
+    a = v > 0
+    for half in (False, True):
+        for comp in (_vdb.COMPRESS_BLOSC, _vdb.COMPRESS_BLOSC | _vdb.COMPRESS_ACTIVE_MASK):
+            path = tmp_path / f"blosc{int(half)}{comp}.vdb"
+            vv = v.astype(np.float16).astype(np.float32) if half else v
+            _vdb.write_vdb(path, vv, a, origin=(-9, 200, 17), compression=comp, half=half)
+            assert np.array_equal(ds.load_vdb(path), _vdb.reference_texture(vv, a, (-9, 200, 17))), (half, comp, real.version)
 
 
 def test_vdb_half_float_grid_and_a_large_tile(tmp_path):

@@ -1176,3 +1176,59 @@ def test_fast_rcp_and_sqrt_are_correctly_rounded_for_every_float_in_range():
     s = tr.debug_math_selftest(1)
     assert s["tested"] == 121 * (1 << 23) and s["mismatches"] == 0, s
     tr.close()
+
+
+@pytest.mark.gpu
+def test_handles_driven_from_several_host_threads_at_once(monkeypatch):
+    """`cloudtrace collect --jobs K` keeps K renderer handles busy from K host threads; the library has no state outside
+    a handle, so whatever the threads do at the same time -- enqueued frame batches of both estimators, point-radiance
+    launches, scatter samples, descriptors, creating and destroying handles -- every result must be what the same
+    calls give one after the other.  Invariants armed (a lost or doubled sample fails the call)."""
+    import threading
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    volumes = [sphere_volume(36 + 4 * i, radius=0.3 + 0.02 * i, seed=60 + i) for i in range(4)]
+
+    def job(i):
+        out = {}
+        for est in (0, 1):
+            tr = ds.CloudTracer(volumes[i], width=96 + 8 * i, height=64, mode=0, cloud_size_m=15000.0, max_depth=300, estimator=est)
+            tr.render_accumulate_async(1, 4)
+            tr.render_accumulate_async(5, 3 + i)
+            out[f"mean{est}"], out[f"m2{est}"], out[f"counters{est}"] = tr.mean(), tr.m2(), tr.counters()
+            if est == 0:
+                pos, d = tr.generate_scatter_samples(128, 7 * i)
+                tasks = ds.make_point_tasks(np.repeat(pos, 3, axis=0), np.repeat(d, 3, axis=0), ids=np.repeat(np.arange(128), 3))
+                for k in range(3):
+                    tasks = tr.point_radiance_launch(tasks, 1 + 5 * k, 5)
+                out["samples"], out["tasks"] = (pos, d), tasks
+                out["descriptors"] = tr.collect_descriptors(pos[:16], d[:16])
+            iv = tr.debug_invariants()
+            assert iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+            tr.close()
+        return out
+
+    serial = [job(i) for i in range(4)]
+    for _ in range(2):
+        results, errors = [None] * 4, []
+
+        def run(i):
+            try:
+                results[i] = job(i)
+            except Exception as e:          # noqa: BLE001 -- reported below, with the thread's index
+                errors.append((i, repr(e)))
+
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for i in range(4):
+            for k, v in serial[i].items():
+                got = results[i][k]
+                if isinstance(v, dict):
+                    assert got == v, (i, k)
+                elif isinstance(v, tuple):
+                    assert all(np.array_equal(a, b) for a, b in zip(got, v)), (i, k)
+                else:
+                    assert got.tobytes() == v.tobytes(), (i, k)

@@ -22,7 +22,6 @@ def main():
     ap.add_argument("--top", type=int, default=60)
     ap.add_argument("--flags", default="")
     ap.add_argument("--asm", default=None, help="use this assembly file instead of compiling")
-    ap.add_argument("--by-function", action="store_true", help="aggregate by (file, enclosing 20-line window) is not available; aggregate by file instead")
     a = ap.parse_args()
     if a.asm:
         text = pathlib.Path(a.asm).read_text()

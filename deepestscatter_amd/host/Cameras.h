@@ -163,7 +163,10 @@ namespace DeepestScatter
         {
             // headless: nobody looks at the screen between saves, so batches are enqueued (a launch hands its
             // unfinished paths to the next one instead of ending with a tail) and the buffers are only read --
-            // convergence test, tonemap, save -- every 40 subframes, where the reference saves (:211-214)
+            // convergence test, tonemap, save -- every 40 subframes, where the reference saves (:211-214).  The reference
+            // tests convergence at every update (10 subframes): headless may stop up to 30 subframes later; the images it
+            // saves at multiples of 40 are the reference's, the final one has those extra samples (headless = false stops
+            // exactly where the reference does)
             const bool look = !headless || subframeId % 40 == 0;
             if (!(look && isConverged()) && !(maxSubframes && subframeId >= maxSubframes))
             {

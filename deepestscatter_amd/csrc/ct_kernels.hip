@@ -1022,7 +1022,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         // (everything idle but samples left: both phases below are no-ops and the loop regenerates)
 
         bool finished = false;
-        if (nb * sc.scatter_den > nm * sc.scatter_num && (nb >= sc.scatter_min || nm == 0)) {
+        const bool do_scatter = nb * sc.scatter_den > nm * sc.scatter_num && (nb >= sc.scatter_min || nm == 0);
+        if (do_scatter) {
             // ---------------- scatter: NEE + new direction (cloudRadianceMaterials.cu:53-61) ----------------
             if (STATS) {
                 st_scat += 1;
@@ -1077,7 +1078,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 }
             }
             w_nee += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(nee_fetched));
-        } else {
+        }
+        if (!do_scatter) {
             // ---------------- march (getNextScatteringEvent, cloud.cuh:87-105) ----------------
             if (STATS) {
                 st_march += 1;
@@ -1739,7 +1741,8 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         // (everything idle but samples left: both phases below are no-ops and the loop regenerates)
 
         bool finished = false;
-        if (nb != 0 && (nb >= sc.scatter_min || nm == 0)) {
+        const bool do_scatter = nb != 0 && (nb >= sc.scatter_min || nm == 0);
+        if (do_scatter) {
             // ---------------- scatter ----------------
             if (STATS) {
                 st_scat += 1;
@@ -1767,7 +1770,8 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                     finished = true;
                 }
             }
-        } else {
+        }
+        if (!do_scatter) {
             // ---------------- tracking visits: a burst, like the march bursts of render_persistent_kernel ----------------
             if (STATS) {
                 st_march += 1;

@@ -1440,17 +1440,28 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
     // if / else-if with a division in each arm made every wave execute both (six IEEE divisions per set-up).  The values
     // are the oracle's: inv = 1 / V; V > 0: tmax = (upper bound - tp) * inv, tdelta = edge * inv; V < 0: tmax = (lower
     // bound - tp) * inv, tdelta = edge * -inv = edge * |inv|; V == 0: both infinite.
-    auto axis = [&](int32_t B, float TP, float V, float &TMAX, float &TDELTA) {
-        const float inv = rcp_(V);   // (IEEE sequence: V can be arbitrarily small.  The short sequence behind a range test measured
-                                     // slower both as a per-lane branch, 4372, and as a wave-uniform one, 4630 against 4680)
+    // The reciprocals: correctly rounded either way.  hipcc's IEEE sequence (eleven instructions, most of them scaling for
+    // subnormal and huge arguments) is needed only when a component of V is tiny -- a direction that is parallel to an axis
+    // to within 2^-60 -- so the wave asks once whether ANY of its lanes has such a component and otherwise takes
+    // rcp_moderate's three instructions per axis (every float of its range checked on the device).
+    // An exact zero counts as tiny here: axis-parallel rays are rare outside tests.
+    const float v_min = fminf(fminf(fabsf(vx), fabsf(vy)), fabsf(vz)), v_max = fmaxf(fmaxf(fabsf(vx), fabsf(vy)), fabsf(vz));
+    const bool moderate = v_min >= 0x1p-60f && v_max <= 0x1p60f;
+    auto axis = [&](int32_t B, float TP, float V, float inv, float &TMAX, float &TDELTA) {
         const int32_t bound = ((B + (V > 0.0f ? 1 : 0)) << sc.mc_shift) - sc.brick_bias;
         const bool moving = V != 0.0f;
         TMAX = moving ? ((float)bound - TP) * inv : inf;
         TDELTA = moving ? edge * fabsf(inv) : inf;
     };
-    axis(d.bx, tpx, vx, d.tmax.x, d.tdelta.x);
-    axis(d.by, tpy, vy, d.tmax.y, d.tdelta.y);
-    axis(d.bz, tpz, vz, d.tmax.z, d.tdelta.z);
+    if (__builtin_amdgcn_ballot_w64(!moderate) == 0ull) {
+        axis(d.bx, tpx, vx, rcp_moderate(vx), d.tmax.x, d.tdelta.x);
+        axis(d.by, tpy, vy, rcp_moderate(vy), d.tmax.y, d.tdelta.y);
+        axis(d.bz, tpz, vz, rcp_moderate(vz), d.tmax.z, d.tdelta.z);
+    } else {
+        axis(d.bx, tpx, vx, rcp_(vx), d.tmax.x, d.tdelta.x);
+        axis(d.by, tpy, vy, rcp_(vy), d.tmax.y, d.tdelta.y);
+        axis(d.bz, tpz, vz, rcp_(vz), d.tmax.z, d.tdelta.z);
+    }
 }
 
 // One cell crossing: t = exit parameter, step along the axis with the smallest tmax

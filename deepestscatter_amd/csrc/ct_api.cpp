@@ -552,8 +552,32 @@ static int create_impl(const CtScene *s, CtHandle h)
         d.mc_gy = (int32_t)cgy;
         d.mc_gz = (int32_t)cgz;
     }
-    HIPCHK(h, launch_inscatter(d, h->d_inscatter, h->stream));
-    HIPCHK(h, launch_build_bricks(h->d_inscatter, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_ibricks, h->stream));
+    // which of the volume's six boundary layers are empty (launch_inscatter: a march that leaves through one of those is over)
+    uint32_t zero_faces = 0;
+    {
+        const uint8_t *t = s->density_host;
+        const auto layer_is_zero = [&](int axis, uint32_t at) {
+            const uint32_t n[3] = { nx, ny, nz };
+            const uint32_t u_axis = (axis + 1) % 3, v_axis = (axis + 2) % 3;
+            for (uint32_t v = 0; v < n[v_axis]; v++) {
+                for (uint32_t u = 0; u < n[u_axis]; u++) {
+                    uint32_t c[3];
+                    c[axis] = at;
+                    c[u_axis] = u;
+                    c[v_axis] = v;
+                    if (t[((size_t)c[2] * ny + c[1]) * nx + c[0]] != 0) {
+                        return false;
+                    }
+                }
+            }
+            return true;
+        };
+        const uint32_t last[3] = { nx - 1, ny - 1, nz - 1 };
+        for (int axis = 0; axis < 3; axis++) {
+            zero_faces |= (layer_is_zero(axis, 0) ? 1u : 0u) << (2 * axis);
+            zero_faces |= (layer_is_zero(axis, last[axis]) ? 1u : 0u) << (2 * axis + 1);
+        }
+    }
     {
         // march bricks (3x4x4 texels, one meta byte per row; DevScene::mbricks).  The two scratch
         // volumes of the distance transform are borrowed from the shadow-volume brick array's
@@ -572,8 +596,20 @@ static int create_impl(const CtScene *s, CtHandle h)
             hipFree(tmp_a);
             return fail(h, CT_E_NOMEM, "out of device memory (distance transform scratch)");
         }
-        const hipError_t e = launch_build_mbricks(h->d_density, nx, ny, nz, mbias, bbias, (int)mgx, (int)bgy, (int)bgz,
-                                                  tmp_a, tmp_b, h->d_mbricks, h->stream);
+        hipError_t e = launch_build_mbricks(h->d_density, nx, ny, nz, mbias, bbias, (int)mgx, (int)bgy, (int)bgz,
+                                            tmp_a, tmp_b, h->d_mbricks, h->stream);
+        if (e == hipSuccess) {
+            // the shadow volume (VDBCloud::InitInScatter): its march towards the sun walks the (dense) march bricks
+            DevScene walk = d;
+            walk.mbricks = h->d_mbricks;
+            walk.m_bias_x = mbias;
+            walk.m_gx = (int32_t)mgx;
+            walk.m_gxy = (int32_t)(mgx * bgy);
+            e = launch_inscatter(walk, h->d_inscatter, zero_faces, h->stream);
+        }
+        if (e == hipSuccess) {
+            e = launch_build_bricks(h->d_inscatter, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_ibricks, h->stream);
+        }
         const hipError_t e2 = hipStreamSynchronize(h->stream);
         // Sparse storage (BASELINE.json configs[4]: "1024^3 sparse brick-compressed density"): CT_FLAG_SPARSE_BRICKS, or
         // CT_SPARSE=0/1 in the environment.  Not the default at any size: measured at 1024^3 / 2048^2 the stored bricks

@@ -105,7 +105,7 @@ hipError_t launch_mbrick_compact(const uint8_t *dense, int gx, int gy, int gz, c
 hipError_t launch_coarse_clearance(const uint8_t *dist, int nx, int ny, int nz, int bias, int cshift, int cgx, int cgy, int cgz,
                                    uint8_t *out, hipStream_t stream);
 hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
-hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, hipStream_t stream);
+hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, uint32_t zero_faces, hipStream_t stream);
 hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream);
 hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);
 hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);

@@ -367,10 +367,11 @@ def test_cpp_cli_collect_with_scene_setups_in_flight_writes_the_same_tables(tmp_
     lst = tmp_path / "setups.txt"
     lst.write_text("# cloud light size\n" + "".join(f"{c} {l} {m}\n" for c, l, m in rows))
     out = tmp_path / "all"
-    r = subprocess.run([str(cli), "collect", f"@{lst}", "--batch", str(batch), "--scene-id", str(first), "--jobs", "3", "--out", str(out)],
-                       capture_output=True, text=True, timeout=900)
+    # (--gpus 0,0: the list of devices the setups are dealt to, here the one GPU twice)
+    r = subprocess.run([str(cli), "collect", f"@{lst}", "--batch", str(batch), "--scene-id", str(first), "--jobs", "3", "--gpus", "0,0",
+                        "--out", str(out)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("collect_timings") == 3 and '"jobs": 3' in r.stdout
+    assert r.stdout.count("collect_timings") == 3 and '"jobs": 3' in r.stdout and '"gpus": 2' in r.stdout
     merged = {}
     for i, (c, l, m) in enumerate(rows):
         one = tmp_path / f"one{i}"

@@ -1232,3 +1232,27 @@ def test_handles_driven_from_several_host_threads_at_once(monkeypatch):
                     assert all(np.array_equal(a, b) for a, b in zip(got, v)), (i, k)
                 else:
                     assert got.tobytes() == v.tobytes(), (i, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [2, 0])
+def test_delta_flights_parallel_to_an_axis_or_nearly_so(mode):
+    """The DELTA kernel's DDA set-up takes a three-instruction reciprocal unless a lane of the wave has a direction
+    component below 2^-60 (then the whole wave takes the compiler's IEEE sequence).  Cameras on the coordinate axes make
+    primary rays with components that are exactly zero (the middle row and column of an even frame), cameras a hair off
+    the axes make tiny ones; waves mix such lanes with ordinary ones.  Every result must be the oracle's either way."""
+    tex = sphere_volume(40, radius=0.42, seed=77)
+    w, h = 64, 48
+    eyes = [(0.0, 0.0, 2.5), (2.5, 0.0, 0.0), (0.0, -2.5, 0.0), (1e-24, 0.0, 2.5), (0.0, 3e-30, -2.5), (2.5, 1e-21, 1e-26)]
+    for eye in eyes:
+        tr, orc = make_pair(tex, w, h, mode=mode, estimator=1, cloud_size_m=4000.0, max_depth=40)
+        up = (0, 1, 0) if abs(eye[1]) < 1 else (0, 0, 1)
+        U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), up, 30.0, w / h)
+        tr.set_camera(eye, U, V, W)
+        orc.set_camera(eye, U, V, W)
+        tr.render_accumulate(1, 3)
+        mean, m2 = orc.render(3)
+        assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2), eye
+        c, o = tr.counters(), orc.counters.as_dict()
+        assert all(c[k] == o[k] for k in ("paths", "box_hits", "density_lookups", "inscatter_lookups", "scatter_events", "depth_capped")), (eye, c, o)
+        tr.close()

@@ -81,8 +81,10 @@ struct CtHandle_ {
     uint32_t jobs_hint = 0;           // batch size the caller asked for last (job lists are built for it)
     // subframes per job at most (cheap groups), and the bounces (x cost unit) a job's lane is expected to run.
     // Re-swept on the final kernels (8 / 256 before): +4.3 % at 512^3, +5.6 % at 1024^3, +2.6 % at 256^3, +1.3 % DELTA
+    // (16 / 48 until the end of round 2; 16 / 16 since: the whole-frame launch does not care, 3288 either way, a rank's
+    // launch of an eighth of the tiles is 1.6 % shorter, 43.6 instead of 44.3 ms)
     uint32_t job_max = 16;
-    float job_work = 48.f;
+    float job_work = 16.f;
     uint32_t q_begin[kQueues + 2] = {}; // job ranges of the per-XCD queues + the shared one
     uint64_t own_pixels = 0, hit_pixels = 0;
     bool queue_dirty = true, order_tuned = false;
@@ -401,6 +403,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     }
     if (const char *e = getenv("CT_JOB_MAX")) {
         h->job_max = (uint32_t)std::min(4096, std::max(1, atoi(e)));
+    }
+    if (s->estimator == CT_EST_DELTA) {
+        h->job_work = 48.f;     // (its cost unit is a bounce; 16 measured 0.4 % slower there)
     }
     if (const char *e = getenv("CT_JOB_WORK")) {
         h->job_work = (float)std::max(1.0, atof(e));

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <new>
 #include <set>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,22 +46,29 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 
+    std::mutex mu;     // two threads may create their first group at once
+
     bool load()
     {
+        std::lock_guard<std::mutex> lock(mu);
         if (lib) {
             return true;
         }
+        void *l = nullptr;
+        std::string why;
         for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (lib) {
+            l = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (l) {
                 break;
             }
+            const char *e = dlerror();   // (returns the message ONCE and clears it)
+            why = e ? e : "?";
         }
-        if (!lib) {
-            error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+        if (!l) {
+            error = "cannot load librccl: " + why;
             return false;
         }
-        auto sym = [&](const char *n) { return dlsym(lib, n); };
+        auto sym = [&](const char *n) { return dlsym(l, n); };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
         Reduce = (decltype(Reduce))sym("ncclReduce");
@@ -69,9 +77,9 @@ struct Rccl {
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
         if (!CommInitAll || !CommDestroy || !Reduce || !GroupStart || !GroupEnd || !GetErrorString) {
             error = "librccl lacks an expected symbol";
-            lib = nullptr;
             return false;
         }
+        lib = l;
         return true;
     }
 };

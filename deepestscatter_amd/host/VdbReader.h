@@ -256,7 +256,10 @@ inline void readCompressedValues(Cursor& in, float* dst, size_t count, const Mas
 {
     int8_t metadata = 6; // NO_MASK_AND_ALL_VALS
     if (fileVersion >= 222) metadata = in.get<int8_t>();
-    auto readOne = [&]() -> float { return fromHalf ? halfToFloat(in.get<uint16_t>()) : in.get<float>(); };
+    // The inactive values are stored with sizeof(ValueT) = 4 bytes whatever the grid's storage precision: a half-float grid
+    // truncates them to half PRECISION (truncateRealToHalf) but writes a float; only the value array goes through
+    // HalfReader (io/Compression.h readCompressedValues / writeCompressedValues).
+    auto readOne = [&]() -> float { return in.get<float>(); };
     float inactive1 = background;
     float inactive0 = (metadata == 0) ? background : -background;
     if (metadata == 2 || metadata == 4 || metadata == 5) {
@@ -406,8 +409,20 @@ void readInternal(Cursor& in, FloatGrid& g, Coord origin, bool fromHalf, std::ve
     Mask childMask(N), valueMask(N);
     childMask.load(in);
     valueMask.load(in);
-    std::vector<float> values(N);
-    readCompressedValues(in, values.data(), N, valueMask, fromHalf, g.compression, g.fileVersion, g.background);
+    std::vector<float> values(N, g.background);
+    if (g.fileVersion < 222) {
+        // before node-mask compression (OPENVDB_FILE_VERSION_NODE_MASK_COMPRESSION = 222) only the childMask.countOff()
+        // values of the slots WITHOUT a child are stored, in slot order (InternalNode::readTopology, oldVersion branch)
+        size_t off = 0;
+        for (size_t n = 0; n < N; n++) off += childMask.on(n) ? 0u : 1u;
+        std::vector<float> packed(off);
+        readCompressedValues(in, packed.data(), off, valueMask, fromHalf, g.compression, g.fileVersion, g.background);
+        for (size_t n = 0, k = 0; n < N; n++) {
+            if (!childMask.on(n)) values[n] = packed[k++];
+        }
+    } else {
+        readCompressedValues(in, values.data(), N, valueMask, fromHalf, g.compression, g.fileVersion, g.background);
+    }
     constexpr int DIM = 1 << LOG2DIM;
     auto childOrigin = [&](size_t n) {
         const int32_t x = (int32_t)(n >> (2 * LOG2DIM)), y = (int32_t)((n >> LOG2DIM) & (DIM - 1)), z = (int32_t)(n & (DIM - 1));
@@ -493,12 +508,14 @@ inline FloatGrid readFirstFloatGrid(const std::string& path)
     // Tree::readTopology
     if (in.get<uint32_t>() != 1) throw std::runtime_error("vdb: multi-buffer trees are not supported");
     // RootNode::readTopology
-    g.background = fromHalf ? halfToFloat(in.get<uint16_t>()) : in.get<float>();
+    // (background and root tile values: sizeof(ValueType) = 4 bytes also in a half-float grid, which only truncates
+    // them to half precision before writing -- RootNode::writeTopology)
+    g.background = in.get<float>();
     const uint32_t numTiles = in.get<uint32_t>(), numChildren = in.get<uint32_t>();
     for (uint32_t i = 0; i < numTiles; i++) {
         Coord o;
         in.read(&o, 12);
-        const float v = fromHalf ? halfToFloat(in.get<uint16_t>()) : in.get<float>();
+        const float v = in.get<float>();
         const bool active = in.get<uint8_t>() != 0;
         g.tiles.push_back(Tile{ o, 4096, v, active });
     }

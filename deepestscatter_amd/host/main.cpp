@@ -179,7 +179,10 @@ namespace
         using Clock = std::chrono::steady_clock;
         const std::vector<SceneSetupLine> setups = readSetups(opt);
         const std::vector<int32_t> devices = opt.devices.empty() ? std::vector<int32_t>{ 0 } : opt.devices;
-        const uint32_t jobs = std::max(1u, std::min<uint32_t>(opt.jobs, (uint32_t)setups.size()));
+        // with --gpus every listed GPU gets at least one worker (jobs < gpus would leave devices idle), and setup i runs on
+        // device i mod gpus whichever worker takes it
+        const uint32_t jobs = std::max(1u, std::min<uint32_t>(std::max<uint32_t>(opt.jobs, opt.devices.empty() ? 1u : (uint32_t)devices.size()),
+                                                             (uint32_t)setups.size()));
         CollectorLog::quiet() = jobs > 1;
         Dataset dataset;
         CollectTotals totals;
@@ -187,7 +190,7 @@ namespace
         std::atomic<uint32_t> next{ 0 };
         std::string firstError;
         const auto t0 = Clock::now();
-        const auto worker = [&](uint32_t w)
+        const auto worker = [&](uint32_t)
         {
             for (uint32_t i = next++; i < setups.size(); i = next++)
             {
@@ -195,7 +198,7 @@ namespace
                 {
                     Dataset mine;
                     CollectTotals mineTotals;
-                    const std::string line = collectOne(opt, setups[i], opt.sceneId + (int32_t)i, devices[w % devices.size()], mine, mineTotals);
+                    const std::string line = collectOne(opt, setups[i], opt.sceneId + (int32_t)i, devices[i % devices.size()], mine, mineTotals);
                     std::lock_guard<std::mutex> g(lock);
                     dataset.merge(mine);
                     totals.radianceDeviceMs += mineTotals.radianceDeviceMs;

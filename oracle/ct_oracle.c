@@ -204,6 +204,12 @@ typedef struct OrcScene {
     const uint8_t *majorant;       /* orc_build_majorants(), needed for DELTA */
     int32_t maj_bias, maj_gx, maj_gy, maj_gz, maj_shift;
     const uint8_t *maj_codes;      /* orc_build_majorants(): per cell q = min(3, 4*min/max), see delta_flight */
+    /* Lazy shadow volume (NULL = `inscatter` is complete).  Otherwise one byte per texel, 0 = `inscatter` does not hold
+     * that texel yet: sampleInScatter evaluates inScatter (inScatter.cu:40-66) for the missing ones of its footprint
+     * and stores them -- the oracle's OWN shadow values for exactly the texels its paths touch, which is what lets a
+     * 512^3 / 1024^3 window test check the product's whole shadow-volume kernel where it matters without a CPU pass
+     * over 1e8-1e9 texels.  `inscatter` must then be writable. */
+    uint8_t *inscatter_valid;
 } OrcScene;
 
 typedef struct OrcCounters {
@@ -229,6 +235,8 @@ typedef struct {
     int32_t estimator;
     const uint8_t *maj, *maj_codes;
     int32_t maj_bias, maj_gx, maj_gy, maj_gz, maj_shift;
+    uint8_t *ins_valid;      /* lazy shadow volume: see OrcScene::inscatter_valid */
+    float sigma_global;      /* estimator 2: majorant of the whole volume */
 } Ctx;
 
 static void ctx_init(Ctx *c, const OrcScene *s)
@@ -274,6 +282,16 @@ static void ctx_init(Ctx *c, const OrcScene *s)
     c->maj_gz = s->maj_gz;
     c->maj_shift = s->maj_shift;
     c->maj_codes = s->maj_codes;
+    c->ins_valid = s->inscatter_valid;
+    c->sigma_global = 0.0f;
+    if (s->estimator == 2) {
+        uint8_t m = 0;
+        const size_t n = (size_t)s->dims[0] * s->dims[1] * s->dims[2];
+        for (size_t i = 0; i < n; i++) {
+            m = s->density[i] > m ? s->density[i] : m;
+        }
+        c->sigma_global = ((float)m / 255.0f) * c->density_multiplier;
+    }
 }
 
 /* Exposes the derived uniforms so tests can compare them with the product's. */
@@ -303,9 +321,36 @@ static inline float sample_cloud(const Ctx *c, v3 pos, OrcCounters *k)
     k->density_lookups++;
     return tex3_fetch(&c->density, pos);
 }
+static uint8_t inscatter_texel(const Ctx *c, int32_t x, int32_t y, int32_t z);
+
+/* Lazy shadow volume: make sure the 8 texels of the footprint at `pos` are there (same addressing as tex3_fetch).
+ * Racing threads store the same byte; the flag is published after the value. */
+static void inscatter_ensure(const Ctx *c, v3 pos)
+{
+    const Tex3 *t = &c->inscatter;
+    const int32_t ix = (int32_t)floorf(fmaf(pos.x, t->sx, -0.5f)), iy = (int32_t)floorf(fmaf(pos.y, t->sy, -0.5f)),
+                  iz = (int32_t)floorf(fmaf(pos.z, t->sz, -0.5f));
+    for (int dz = 0; dz < 2; dz++) {
+        for (int dy = 0; dy < 2; dy++) {
+            for (int dx = 0; dx < 2; dx++) {
+                const int32_t x = clampi(ix + dx, 0, t->nx - 1), y = clampi(iy + dy, 0, t->ny - 1), z = clampi(iz + dz, 0, t->nz - 1);
+                const size_t at = ((size_t)z * t->ny + y) * t->nx + x;
+                if (!__atomic_load_n(&c->ins_valid[at], __ATOMIC_ACQUIRE)) {
+                    const uint8_t v = inscatter_texel(c, x, y, z);
+                    __atomic_store_n((uint8_t *)&t->texels[at], v, __ATOMIC_RELAXED);
+                    __atomic_store_n(&c->ins_valid[at], 1, __ATOMIC_RELEASE);
+                }
+            }
+        }
+    }
+}
+
 static inline float sample_inscatter(const Ctx *c, v3 pos, OrcCounters *k)
 {
     k->inscatter_lookups++;
+    if (c->ins_valid) {
+        inscatter_ensure(c, pos);
+    }
     return tex3_fetch(&c->inscatter, pos);
 }
 
@@ -486,9 +531,46 @@ static Event delta_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCount
     }
 }
 
+/* estimator 2 -- an INDEPENDENT check of the DELTA kernel, not its twin: textbook Woodcock tracking of the same medium
+ * with ONE majorant for the whole volume -- no cell grid, no DDA, no lower-bound codes, libm's logf instead of
+ * ct_fmath.h's, a plain division.  It shares nothing with delta_flight (or with the kernel) but the sampler, and consumes
+ * the random stream differently, so it agrees with them statistically only: tests compare means within the combined
+ * confidence interval.  The flight ends when it leaves the slack box: a straight line cannot come back, a collision out
+ * there ends the path (cloudRadianceMaterials.cu:49-52), and so does leaving the grid in delta_flight. */
+static Event global_majorant_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCounters *k)
+{
+    Event e = { 0, pos, 1.0f };
+    if (!(c->sigma_global > 0.0f)) {
+        return e;
+    }
+    double t = 0.0;
+    for (;;) {
+        const float u = orc_rnd(seed);
+        t += (double)(-logf(1.0f - u)) / (double)c->sigma_global;
+        const v3 p = v3_make((float)(pos.x + dir.x * t), (float)(pos.y + dir.y * t), (float)(pos.z + dir.z * t));
+        if (!in_box(c, p)) {
+            e.pos = p;
+            return e;
+        }
+        const float z = orc_rnd(seed);
+        if (z * c->sigma_global < sample_cloud(c, p, k) * c->density_multiplier) {
+            e.scattered = 1;
+            e.pos = p;
+            return e;
+        }
+    }
+}
+
 /* One free flight with the scene's estimator; MARCH draws its random number first (cloud.cuh:120). */
 static Event free_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCounters *k)
 {
+    if (c->estimator == 2) {
+        if (!in_box(c, pos)) {
+            const Event e = { 0, pos, 1.0f };
+            return e;
+        }
+        return global_majorant_flight(c, seed, pos, dir, k);
+    }
     if (c->estimator == 1) {
         /* getNextScatteringEvent only marches while isInBox(pos) (cloud.cuh:87): a flight that STARTS outside the
          * slack box does nothing.  The bounce loops of totalRadiance / multipleScatterSunRadiance test that before every
@@ -942,16 +1024,36 @@ ORC_API int32_t orc_point_task_merge(OrcPointTask *into, const OrcPointTask *oth
  * Sample THEN step; marches 1/sampleStep steps toward -lightDirection; early out when
  * T*255 < 1; stores uchar(T*255) truncating.  `s->inscatter` is ignored.
  * ------------------------------------------------------------------------------------------ */
+/* one texel of the shadow volume: inScatter.cu:40-66 for launch index (x, y, z) */
+static uint8_t inscatter_texel(const Ctx *c, int32_t x, int32_t y, int32_t z)
+{
+    const int32_t nx = c->density.nx, ny = c->density.ny, nz = c->density.nz;
+    const int32_t maxn = nx > ny ? (nx > nz ? nx : nz) : (ny > nz ? ny : nz);
+    const float max_size = (float)maxn;
+    const float min_scale = fminf(fminf(c->tscale.x, c->tscale.y), c->tscale.z);
+    const v3 step_to_light = v3_scale(v3_neg(v3_normalize(c->light_dir)), c->sample_step);
+    const int step_count = (int)(1 / c->sample_step);
+    OrcCounters k = { 0, 0, 0, 0, 0, 0 };
+    v3 p = v3_make((float)x / max_size, (float)y / max_size, (float)z / max_size);
+    p = v3_div(p, min_scale);
+    float transmittance = 1;
+    for (int i = 0; i < step_count; i++) {
+        const float density = sample_cloud(c, p, &k) * c->density_multiplier;
+        const float extinction = density * c->sample_step;
+        transmittance *= ct_expf(-extinction);
+        p = v3_add(p, step_to_light);
+        if (transmittance * 255.f < 1.f) {
+            break;
+        }
+    }
+    return (uint8_t)(transmittance * 255.f);
+}
+
 ORC_API void orc_inscatter(const OrcScene *s, uint8_t *out, int32_t threads)
 {
     Ctx c;
     ctx_init(&c, s);
     const int32_t nx = c.density.nx, ny = c.density.ny, nz = c.density.nz;
-    const int32_t maxn = nx > ny ? (nx > nz ? nx : nz) : (ny > nz ? ny : nz);
-    const float max_size = (float)maxn;
-    const float min_scale = fminf(fminf(c.tscale.x, c.tscale.y), c.tscale.z);
-    const v3 step_to_light = v3_scale(v3_neg(v3_normalize(c.light_dir)), c.sample_step);
-    const int step_count = (int)(1 / c.sample_step);
 #ifdef _OPENMP
     if (threads <= 0) {
         threads = omp_get_max_threads();
@@ -961,24 +1063,30 @@ ORC_API void orc_inscatter(const OrcScene *s, uint8_t *out, int32_t threads)
 #endif
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
     for (int32_t z = 0; z < nz; z++) {
-        OrcCounters k = { 0, 0, 0, 0, 0, 0 };
         for (int32_t y = 0; y < ny; y++) {
             for (int32_t x = 0; x < nx; x++) {
-                v3 p = v3_make((float)x / max_size, (float)y / max_size, (float)z / max_size);
-                p = v3_div(p, min_scale);
-                float transmittance = 1;
-                for (int i = 0; i < step_count; i++) {
-                    const float density = sample_cloud(&c, p, &k) * c.density_multiplier;
-                    const float extinction = density * c.sample_step;
-                    transmittance *= ct_expf(-extinction);
-                    p = v3_add(p, step_to_light);
-                    if (transmittance * 255.f < 1.f) {
-                        break;
-                    }
-                }
-                out[((size_t)z * ny + y) * nx + x] = (uint8_t)(transmittance * 255.f);
+                out[((size_t)z * ny + y) * nx + x] = inscatter_texel(&c, x, y, z);
             }
         }
+    }
+}
+
+/* The same for a list of texels (xyz[3i..3i+2]): what the 256^3 / 512^3 / 1024^3 shadow-volume tests compare the
+ * product's inscatter_kernel with, texel by texel, without a CPU pass over the whole volume. */
+ORC_API void orc_inscatter_texels(const OrcScene *s, const uint32_t *xyz, uint64_t count, uint8_t *out, int32_t threads)
+{
+    Ctx c;
+    ctx_init(&c, s);
+#ifdef _OPENMP
+    if (threads <= 0) {
+        threads = omp_get_max_threads();
+    }
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)count; i++) {
+        out[i] = inscatter_texel(&c, (int32_t)xyz[3 * i], (int32_t)xyz[3 * i + 1], (int32_t)xyz[3 * i + 2]);
     }
 }
 

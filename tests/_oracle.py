@@ -49,6 +49,7 @@ class OrcScene(C.Structure):
         ("maj_gz", C.c_int32),
         ("maj_shift", C.c_int32),
         ("maj_codes", C.c_void_p),
+        ("inscatter_valid", C.c_void_p),
     ]
 
 
@@ -120,6 +121,7 @@ def lib(fast: bool = False):
     L.orc_point_radiance.argtypes = [C.POINTER(OrcScene), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(OrcCounters)]
     L.orc_inscatter.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_int32]
+    L.orc_inscatter_texels.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32]
     L.orc_point_radiance_launch.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.POINTER(OrcCounters), C.c_int32]
     L.orc_majorant_grid.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
@@ -201,7 +203,7 @@ class Oracle:
     estimator: int = 0
     threads: int = 0
     fast: bool = False
-    inscatter: np.ndarray | None = None
+    inscatter: np.ndarray | str | None = None   # None: computed here; "lazy": texel by texel as paths touch it; "none": never
     counters: OrcCounters = field(default_factory=OrcCounters)
 
     def __post_init__(self):
@@ -246,12 +248,27 @@ class Oracle:
             s.maj_codes = self.majorant_codes.ctypes.data
             s.maj_bias, s.maj_gx, s.maj_gy, s.maj_gz, s.maj_shift = bias, gx, gy, gz, shift
         self.scene = s
+        self.inscatter_valid = None
         if self.inscatter is None:
             self.inscatter = np.empty_like(self.density)
             self.L.orc_inscatter(C.byref(s), _ptr(self.inscatter), self.threads)
+        elif isinstance(self.inscatter, str) and self.inscatter == "lazy":
+            # the oracle's own shadow values for the texels its paths touch (OrcScene::inscatter_valid)
+            self.inscatter = np.zeros_like(self.density)
+            self.inscatter_valid = np.zeros_like(self.density)
+            s.inscatter_valid = self.inscatter_valid.ctypes.data
+        elif isinstance(self.inscatter, str) and self.inscatter == "none":
+            self.inscatter = np.zeros_like(self.density)     # for callers that only use inscatter_texels()
         else:
             self.inscatter = np.ascontiguousarray(self.inscatter, dtype=np.uint8)
         s.inscatter = self.inscatter.ctypes.data
+
+    def inscatter_texels(self, xyz: np.ndarray) -> np.ndarray:
+        """inScatter (inScatter.cu:40-66) at the texels xyz[i] = (x, y, z): uint8 [len(xyz)]."""
+        xyz = np.ascontiguousarray(xyz, np.uint32).reshape(-1, 3)
+        out = np.empty(len(xyz), np.uint8)
+        self.L.orc_inscatter_texels(C.byref(self.scene), _ptr(xyz), len(xyz), _ptr(out), self.threads)
+        return out
 
     def set_camera(self, eye, U, V, W):
         self.scene.eye[:] = [float(v) for v in eye]

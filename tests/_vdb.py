@@ -188,7 +188,10 @@ class _Writer:
         self.blosc_memcpy, self.force_all = blosc_memcpy, force_all_values
 
     def scalar(self, v: float) -> bytes:
-        return np.float16(v).tobytes() if self.half else struct.pack("<f", v)
+        # background, root tile values and a node's inactive values are written with sizeof(ValueType) = 4 bytes; a
+        # half-float grid truncates them to half PRECISION first (io::truncateRealToHalf) -- only the value arrays are
+        # stored as 16-bit halves (RootNode::writeTopology, io::writeCompressedValues)
+        return struct.pack("<f", float(np.float16(v)) if self.half else v)
 
     def data(self, values: np.ndarray) -> bytes:
         raw = values.astype(np.float16 if self.half else np.float32).tobytes()
@@ -304,6 +307,13 @@ def write_vdb(path, values: np.ndarray, active: np.ndarray, origin=(0, 0, 0), ti
             value_mask[offset(o)] = a
         return child_mask, value_mask, vals, [o for _, o in sorted(order)]
 
+    def internal_values(vals, child_mask, value_mask):
+        # InternalNode::writeTopology: all NUM_VALUES values since file version 222 (node-mask compression); before that only
+        # the childMask.countOff() values of the slots without a child, in slot order
+        if version < 222:
+            return w.compressed_values(vals[~child_mask], value_mask[~child_mask], background)
+        return w.compressed_values(vals, value_mask, background)
+
     topo = bytearray()
     buffers = bytearray()
     topo += struct.pack("<I", 1)                                     # Tree::writeTopology: buffer count
@@ -315,12 +325,12 @@ def write_vdb(path, values: np.ndarray, active: np.ndarray, origin=(0, 0, 0), ti
         topo += struct.pack("<3i", *r)
         l2_tiles = [(o, v, a) for level, o, v, a in tiles if level == 2 and tuple(c & ~4095 for c in o) == r]
         cm, vm, vals, l2_order = node_arrays(5, 7, r, roots[r].keys(), l2_tiles)
-        topo += _mask_bytes(cm) + _mask_bytes(vm) + w.compressed_values(vals, vm, background)
+        topo += _mask_bytes(cm) + _mask_bytes(vm) + internal_values(vals, cm, vm)
         for n2 in l2_order:
             kids = [k for k in leaves if tuple(c & ~127 for c in k) == n2]
             l1_tiles = [(o, v, a) for level, o, v, a in tiles if level == 1 and tuple(c & ~127 for c in o) == n2]
             cm2, vm2, vals2, leaf_order = node_arrays(4, 3, n2, kids, l1_tiles)
-            topo += _mask_bytes(cm2) + _mask_bytes(vm2) + w.compressed_values(vals2, vm2, background)
+            topo += _mask_bytes(cm2) + _mask_bytes(vm2) + internal_values(vals2, cm2, vm2)
             for k in leaf_order:
                 v, m = leaves[k]
                 topo += _mask_bytes(m.reshape(-1))                   # LeafNode::writeTopology: x slowest, z fastest

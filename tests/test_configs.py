@@ -80,6 +80,16 @@ def cloud_1024():
     return ds.make_procedural_cloud(1024)
 
 
+def test_config4_shadow_volume_against_the_oracle(cloud_1024):
+    """The 1024^3 shadow volume (where inscatter_kernel's clearance cap of 127 texels is reached and a march step
+    advances two texels) against inScatter.cu:40-66 restated texel by texel, on >= 1e5 texels of every class."""
+    from test_parity_gaps import check_shadow_volume
+    tr = ds.CloudTracer(cloud_1024, width=64, height=64)
+    got = tr.inscatter()
+    tr.close()
+    assert check_shadow_volume(cloud_1024, got, seed=1024) >= 100_000
+
+
 @pytest.mark.parametrize("estimator,sparse", [(0, False), (1, False), (0, True)])
 def test_config4_1024_2048x2048_window_and_no_lost_jobs(cloud_1024, estimator, sparse, monkeypatch):
     """configs[4] on one GPU: 1024^3 density (dense march bricks, and the sparse brick-compressed storage of

@@ -775,7 +775,10 @@ def test_north_star_parity_after_1024_spp_on_a_window():
     tr.synchronize()
     assert tr.debug_suspended() > 10000
     mean, m2 = tr.mean(), tr.m2()
-    orc = O.Oracle(tex, w, h, fast=True, inscatter=tr.inscatter())
+    # The oracle does NOT borrow the product's shadow volume here: it evaluates inScatter (inScatter.cu:40-66) itself for
+    # every texel its paths' NEE lookups touch (OrcScene::inscatter_valid), so the window checks the march AND the
+    # shadow volume it reads; the touched texels are then compared with the product's volume one by one.
+    orc = O.Oracle(tex, w, h, fast=True, inscatter="lazy")
     x0, y0 = 500, 520
     win = (x0, y0, x0 + 16, y0 + 16)
     ref_mean, ref_m2 = orc.render(1024, window=win)
@@ -784,6 +787,9 @@ def test_north_star_parity_after_1024_spp_on_a_window():
     assert rel_l2(got, ref) <= 1e-3
     assert np.array_equal(got, ref)
     assert np.array_equal(m2[y0:y0 + 16, x0:x0 + 16], ref_m2[y0:y0 + 16, x0:x0 + 16])
+    touched = orc.inscatter_valid.astype(bool)
+    assert touched.sum() > 1_000_000                    # the window's paths wander through the whole body of the cloud
+    assert np.array_equal(tr.inscatter()[touched], orc.inscatter[touched])
     tr.close()
 
 

@@ -442,3 +442,40 @@ def test_delta_flight_that_starts_outside_the_slack_box_does_nothing():
             assert c["box_hits"] == c["paths"] == 3 * w * h, (est, mode, c)     # every ray's backward extension meets the box
             assert c["density_lookups"] == 0 and c["scatter_events"] == 0, (est, mode, c)
             assert np.all(mean[..., :3] == 0)
+
+
+def test_lazy_shadow_volume_and_texel_lists_equal_the_full_precompute():
+    """The oracle's three ways to a shadow texel -- the whole-volume loop, a list of texels, on demand under the NEE
+    lookups of a render -- are one function (inScatter.cu:40-66) and must agree; the big GPU tests rely on the last two."""
+    import deepestscatter_amd as ds
+    tex = ds.make_procedural_cloud(48)
+    full = O.Oracle(tex, 24, 24, fast=True)
+    rng = np.random.default_rng(7)
+    xyz = rng.integers(0, 48, (4000, 3)).astype(np.uint32)
+    assert np.array_equal(full.inscatter_texels(xyz), full.inscatter[xyz[:, 2], xyz[:, 1], xyz[:, 0]])
+    lazy = O.Oracle(tex, 24, 24, fast=True, inscatter="lazy")
+    a, a2 = full.render(6)
+    b, b2 = lazy.render(6)
+    assert np.array_equal(a, b) and np.array_equal(a2, b2) and full.counters.as_dict() == lazy.counters.as_dict()
+    touched = lazy.inscatter_valid.astype(bool)
+    assert 1000 < touched.sum() < touched.size and np.array_equal(lazy.inscatter[touched], full.inscatter[touched])
+
+
+def test_independent_woodcock_tracker_agrees_with_the_delta_twin():
+    """estimator 2 (one global majorant, libm logf; shares nothing with delta_flight but the sampler) against estimator 1
+    (the DELTA kernel's twin) on a small cloud: the same radiance within the combined confidence interval, with ~20x the
+    lookups -- what the GPU test test_delta_kernel_agrees_with_an_independent_woodcock_tracker does at full size."""
+    import deepestscatter_amd as ds
+    tex = ds.make_procedural_cloud(48)
+    w = h = 32
+    spp = 192
+    grid = O.Oracle(tex, w, h, fast=True, estimator=1)
+    glob = O.Oracle(tex, w, h, fast=True, estimator=2, inscatter=grid.inscatter)
+    win = (10, 10, 26, 26)
+    am, a2 = grid.render(spp, window=win)
+    bm, b2 = glob.render(spp, window=win)
+    a, va = am[10:26, 10:26, 0].astype(np.float64), a2[10:26, 10:26, 0].astype(np.float64) / (spp - 1)
+    b, vb = bm[10:26, 10:26, 0].astype(np.float64), b2[10:26, 10:26, 0].astype(np.float64) / (spp - 1)
+    se = np.sqrt((va.mean() + vb.mean()) / (spp * 256))
+    assert b.mean() > 0.05 and abs(a.mean() - b.mean()) <= 1.96 * se
+    assert glob.counters.density_lookups > 5 * grid.counters.density_lookups

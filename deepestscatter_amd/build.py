@@ -19,7 +19,7 @@ ROOT = PKG.parent
 LIB = PKG / "libcloudtrace.so"
 
 SOURCES = ["ct_kernels.hip", "ct_group.hip", "ct_api.cpp", "ct_host.cpp"]
-HEADERS = [CSRC / "ct_device.hpp", CSRC / "ct_internal.hpp", ROOT / "include" / "cloudtrace.h",
+HEADERS = [CSRC / "ct_device.hpp", CSRC / "ct_internal.hpp", CSRC / "ct_exchange.hpp", ROOT / "include" / "cloudtrace.h",
            ROOT / "include" / "ct_fmath.h", PKG / "host" / "VdbReader.h"]
 
 # -ffp-contract=off is part of the numeric contract (include/ct_fmath.h): results must be

@@ -380,6 +380,8 @@ class CloudTracer:
         # running after they had found the job queue empty (0.5 ms bins)
         d["wave_end_hist_5ms"] = [int(v) for v in out[16:40]]
         d["wave_end_minus_drained_hist_0p5ms"] = [int(v) for v in out[40:64]]
+        d["raw"] = [int(v) for v in out]
+        d["watchdog"] = int(out[63])     # exchange kernels: waves that gave up on a bounded wait (must be 0)
         return d
 
     def debug_suspended(self) -> int:

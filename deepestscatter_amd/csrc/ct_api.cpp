@@ -120,6 +120,10 @@ struct CtHandle_ {
 
     size_t volume_bytes = 0;
     LaunchShape shape{ 1024, 256, false };
+    // CT_EXCHANGE=1: the estimator kernels with a block-wide exchange of paths between waves (ct_exchange.hpp) render the
+    // batches whose job order is tuned; the cost-measuring launch of a pose keeps the per-lane kernels
+    bool exchange = false;
+    LaunchShape xshape{ 256, 1024, false };
     uint32_t subframes = 0;
     double render_ms = 0, accum_ms = 0;
     uint64_t launches = 0;
@@ -321,6 +325,13 @@ static int create_impl(const CtScene *s, CtHandle h)
         h->debug_invariants = atoi(e) != 0;
     }
     h->shape.stats = getenv("CT_STATS") != nullptr || h->debug_invariants;
+    if (const char *e = getenv("CT_EXCHANGE")) {
+        h->exchange = atoi(e) != 0 && s->estimator == CT_EST_DELTA;
+    }
+    if (h->exchange) {
+        h->xshape = exchange_shape(s->device);
+        h->xshape.stats = h->shape.stats;
+    }
 
     // ---- uniforms: VDBCloud::setupVolumeVariables (VDBCloud.cpp:98-111), Sun::init (Sun.cpp:13-18)
     DevScene &d = h->dev;
@@ -723,6 +734,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, hipEventCreate(&h->ev_flush1));
     if (const char *e = getenv("CT_CONTINUATION")) {
         h->continuation = atoi(e) != 0;
+    }
+    if (h->exchange) {
+        h->continuation = false;   // (the exchange kernels run every path to its end)
     }
     for (auto &sl : h->slots) {
         HIPCHK(h, dmalloc(&sl.cont, h->cont_capacity * (s->estimator == CT_EST_DELTA ? kContWordsDelta : kContWords)));
@@ -1230,7 +1244,9 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         }
     } else {
         if (h->n_jobs != 0 || ba.cont_in) {
-            if (h->scene.estimator == CT_EST_DELTA) {
+            if (h->exchange && !ba.cost && !ba.cont_in && !ba.cont_out && h->scene.estimator == CT_EST_DELTA) {
+                HIPCHK(h, launch_render_delta_x(h->dev, ba, h->xshape, h->stream));
+            } else if (h->scene.estimator == CT_EST_DELTA) {
                 HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
             } else {
                 HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));

@@ -73,6 +73,7 @@ struct LaunchShape {
     int blocks;
     int threads;
     bool stats;   // launch the diagnostics build of the kernel (CT_STATS / CT_DEBUG_INVARIANTS at ct_create)
+    uint32_t pool_slots = 0;   // exchange kernels (ct_exchange.hpp): slots of the block's path pool in LDS
 };
 
 // Evenly split job list (no locality information): point tasks, first launches.
@@ -151,5 +152,8 @@ hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const fl
                               uint32_t count, float level0, float voxel_m, float cloud_size_m, uint8_t *out,
                               hipStream_t stream);
 LaunchShape persistent_shape(int device, bool delta);
+// The estimators with a block-wide exchange of paths between waves (ct_exchange.hpp): one 1024-thread block per CU.
+LaunchShape exchange_shape(int device);
+hipError_t launch_render_delta_x(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 
 } // namespace ct

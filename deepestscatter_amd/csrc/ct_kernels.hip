@@ -2050,6 +2050,8 @@ hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchSh
     return hipGetLastError();
 }
 
+#include "ct_exchange.hpp"
+
 LaunchShape persistent_shape(int device, bool delta)
 {
     hipDeviceProp_t prop;

@@ -129,7 +129,7 @@ def test_delta_kernel_agrees_with_an_independent_woodcock_tracker(n, size, win, 
     rm, rm2 = orc.render(spp, window=(x0, y0, x0 + win, y0 + win))
     a, va = mean[y0:y0 + win, x0:x0 + win, 0].astype(np.float64), m2[y0:y0 + win, x0:x0 + win, 0].astype(np.float64) / (spp - 1)
     b, vb = rm[y0:y0 + win, x0:x0 + win, 0].astype(np.float64), rm2[y0:y0 + win, x0:x0 + win, 0].astype(np.float64) / (spp - 1)
-    assert b.mean() > 0.05
+    assert b.mean() > (1e-3 if mode == 2 else 0.05)      # the window sees the cloud (single scatter is dim)
     se = np.sqrt((va.mean() + vb.mean()) / (spp * win * win))          # s.e. of the difference of the window means
     assert abs(a.mean() - b.mean()) <= 1.96 * se + 1e-12, (a.mean(), b.mean(), se)
     z = (a - b) / np.sqrt((va + vb) / spp + 1e-30)

@@ -37,14 +37,16 @@ constexpr uint32_t kXRing = 1u << kXRingLog;        // entries per ring (>= slot
 constexpr uint32_t kXEmpty = 0x80000000u;           // B.w: the slot holds no path -- whoever takes it starts a new sample
 constexpr uint32_t kXNoSlot = 0xffffffffu;
 constexpr uint32_t kXSpinLimit = 1u << 22;         // watchdog: no wait inside the kernel is unbounded (a fault must not hang the GPU)
-constexpr unsigned long long kXWatchdogTicks = 3000000000ull;   // 30 s of the 100 MHz wall clock
+constexpr unsigned long long kXWatchdogTicks = 800000000ull;    // 8 s of the 100 MHz wall clock (a launch is well under a second)
 
 struct XCtl {
     uint32_t b_tail, b_head;   // BOUNCE ring: collided paths waiting for a scatter batch
-    uint32_t t_tail, t_head;   // TRACK ring: scattered paths (and empty slots) waiting for a tracking lane
+    uint32_t t_tail, t_head;   // TRACK ring: scattered paths waiting for a tracking lane
+    uint32_t f_tail, f_head;   // FREE ring: slots without a path, for the lanes that start new samples
     int32_t live;              // paths of this block that have started and not ended
     uint32_t drained_waves;    // waves that will not start another sample
-    uint32_t pad[2];
+    uint32_t no_jobs;          // some wave has found every job queue empty (then it is empty for all)
+    uint32_t pad[3];
 };
 
 #define X_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
@@ -53,6 +55,32 @@ struct XCtl {
 CT_DEV uint32_t x_load(const uint32_t *p)
 {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+
+// One look at the block's control words per scheduler visit: nine LDS reads in flight together instead of one
+// round trip per decision.  The values are hints (a ring is re-read by the pop that acts on it); readfirstlane makes
+// the decisions scalar branches.
+struct XSnap {
+    uint32_t b_pending, t_pending, f_pending, drained_waves, no_jobs;
+    int32_t live;
+};
+
+CT_DEV XSnap x_snapshot(const XCtl *c)
+{
+    const uint32_t bt = __hip_atomic_load(&c->b_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), bh = __hip_atomic_load(&c->b_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t tt = __hip_atomic_load(&c->t_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), th = __hip_atomic_load(&c->t_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t ft = __hip_atomic_load(&c->f_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), fh = __hip_atomic_load(&c->f_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t dw = __hip_atomic_load(&c->drained_waves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t nj = __hip_atomic_load(&c->no_jobs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int32_t lv = __hip_atomic_load(&c->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    XSnap s;
+    s.b_pending = __builtin_amdgcn_readfirstlane(bt - bh);
+    s.t_pending = __builtin_amdgcn_readfirstlane(tt - th);
+    s.f_pending = __builtin_amdgcn_readfirstlane(ft - fh);
+    s.drained_waves = __builtin_amdgcn_readfirstlane(dw);
+    s.no_jobs = __builtin_amdgcn_readfirstlane(nj);
+    s.live = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)lv);
+    return s;
 }
 
 // The lanes with `mine` append their slot ids to a ring.  (Their slot writes come first: release.)
@@ -123,7 +151,7 @@ CT_DEV uint32_t x_pop(uint16_t *ring, uint32_t *head, const uint32_t *tail, uint
 }
 
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, BatchArgs ba, uint32_t n_slots)
+__global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, BatchArgs ba, uint32_t n_slots, uint32_t n_scatter_waves)
 {
     __shared__ MieLds lds;
     __shared__ uint32_t maj_words[kMajCellsMax / 4];
@@ -132,7 +160,7 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
     __shared__ XCtl ctl;
     extern __shared__ uint4 x_pool[];
     uint4 *const slotA = x_pool, *const slotB = slotA + n_slots, *const slotC = slotB + n_slots;
-    uint16_t *const ringB = (uint16_t *)(slotC + n_slots), *const ringT = ringB + kXRing;
+    uint16_t *const ringB = (uint16_t *)(slotC + n_slots), *const ringT = ringB + kXRing, *const ringF = ringT + kXRing;
     {
         const uint32_t words = ((uint32_t)(sc.mc_gx * sc.mc_gy * sc.mc_gz) + 3u) >> 2;
         const uint32_t *src = (const uint32_t *)sc.maj_cells, *srcc = (const uint32_t *)sc.maj_codes;
@@ -145,22 +173,22 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
             const float sb = ((float)threadIdx.x * (1.0f / 255.0f)) * sc.density_multiplier;
             sigma_table[threadIdx.x] = make_float2(sb, 1.0f / sb);
         }
-        // the slots beyond the resident ones start in the TRACK ring as empty slots (lap 0: parity 0); every other ring
-        // entry carries the parity of "lap -1"
+        // the slots beyond the resident ones start in the FREE ring (lap 0: parity 0); every other ring entry carries the
+        // parity of "lap -1"
         const uint32_t spare = n_slots - (uint32_t)kXThreads;
         for (uint32_t i = threadIdx.x; i < kXRing; i += blockDim.x) {
             ringB[i] = 0x8000u;
-            ringT[i] = (i < spare) ? (uint16_t)((uint32_t)kXThreads + i) : (uint16_t)0x8000u;
-        }
-        for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x) {
-            slotB[i] = make_uint4(0u, 0u, 0u, kXEmpty);
+            ringT[i] = 0x8000u;
+            ringF[i] = (i < spare) ? (uint16_t)((uint32_t)kXThreads + i) : (uint16_t)0x8000u;
         }
         if (threadIdx.x == 0) {
             ctl.b_tail = ctl.b_head = 0u;
-            ctl.t_head = 0u;
-            ctl.t_tail = spare;
+            ctl.t_tail = ctl.t_head = 0u;
+            ctl.f_head = 0u;
+            ctl.f_tail = spare;
             ctl.live = 0;
-            ctl.drained_waves = 0u;
+            ctl.drained_waves = n_scatter_waves;   // (a scatter wave never starts a sample)
+            ctl.no_jobs = 0u;
         }
     }
     const uint8_t *lds_maj = (const uint8_t *)maj_words;
@@ -184,6 +212,92 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
     const unsigned long long t_start = wall_clock64();
     uint32_t visit = 0;
 
+    // The scatter phase of render_delta_kernel (cloudRadianceMaterials.cu:53-61) for up to 64 paths of the BOUNCE ring.
+    auto scatter_batch = [&](const XSnap &snap) {
+        uint32_t id = 0;
+        bool got;
+        const uint32_t n = x_pop(ringB, &ctl.b_head, &ctl.b_tail, ~0ull, lane, id, got, bad);
+        if (n == 0u) {
+            return;
+        }
+        bool onward = false;
+        if (STATS) {
+            st_scat += 1;
+            st_scat_l += n;
+        }
+        if (got) {
+            const uint4 a = slotA[id], b = slotB[id], c = slotC[id];
+            const f3 pos = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+            f3 d = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+            f3 rad = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+            uint32_t s = a.w, depth = b.w;
+            const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1u) : false);
+            const NeeLoads nee = in_scattering_issue(sc, pos, d, chopped);
+            c_il += 1;
+            bool go = (MODE != 2);
+            if (go) {
+                d = new_direction(lds.cdf, lds.guide, s, d);
+                depth++;
+                if (depth == sc.max_depth) {
+                    c_cap += 1;
+                    go = false;
+                }
+            }
+            rad = add3(rad, in_scattering_finish(sc, nee, pos));
+            if (go) {
+                slotA[id].w = s;
+                slotB[id] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), depth);
+                slotC[id] = make_uint4(__float_as_uint(rad.x), __float_as_uint(rad.y), __float_as_uint(rad.z), c.w);
+                onward = true;
+            } else {
+                ba.frames[c.w] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                if (STATS) {
+                    iv_written += 1;
+                }
+            }
+        }
+        const uint32_t n_onward = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(onward));
+        ended_paths += (int32_t)(n - n_onward);
+        x_push(ringT, &ctl.t_tail, onward, id, lane);
+        // a finished path's slot is free for a new sample while some wave may still start one
+        if (n_onward != n && snap.drained_waves != (uint32_t)kXWaves) {
+            x_push(ringF, &ctl.f_tail, got && !onward, id, lane);
+        }
+    };
+    auto flush_ended = [&]() {
+        if (ended_paths != 0) {
+            if (lane == 0) {
+                __hip_atomic_fetch_add(&ctl.live, -ended_paths, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            ended_paths = 0;
+        }
+    };
+
+    if ((threadIdx.x >> 6) < n_scatter_waves) {
+        // ---------------- a SCATTER wave: batches of 64 collided paths, nothing else ----------------
+        for (;;) {
+            visit += 1;
+            if ((visit & 1023u) == 0u && wall_clock64() - t_start > kXWatchdogTicks) {
+                bad = true;
+            }
+            if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+                break;
+            }
+            const XSnap snap = x_snapshot(&ctl);
+            // a full batch; a partial one when the tracking lanes have nothing to adopt (the supply is short, or it is the tail)
+            if (snap.b_pending >= 64u || (snap.b_pending != 0u && snap.t_pending == 0u)) {
+                scatter_batch(snap);
+                flush_ended();
+            } else if (snap.drained_waves == (uint32_t)kXWaves && snap.live == 0) {
+                break;
+            } else {
+                __builtin_amdgcn_s_sleep(2);
+                if (STATS) {
+                    st_spin += 1;
+                }
+            }
+        }
+    } else
     for (;;) {
         visit += 1;
         if ((visit & 1023u) == 0u && wall_clock64() - t_start > kXWatchdogTicks) {
@@ -192,66 +306,29 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
             break;   // give up (results are wrong): the grid must drain whatever happened
         }
-        // ---------------- (1) scatter duty: a batch of collided paths, whichever lanes they collided in ----------------
+        const XSnap snap = x_snapshot(&ctl);
+        // ---------------- (1) scatter duty of a TRACKING wave ----------------
         {
-            const uint32_t pending = x_load(&ctl.b_tail) - x_load(&ctl.b_head);
-            const bool marching_any = __builtin_amdgcn_ballot_w64(state == ST_MARCH) != 0ull;
-            if (pending >= 64u || (pending != 0u && !marching_any && drained && q_next == q_end)) {
-                uint32_t id = 0;
-                bool got;
-                const uint32_t n = x_pop(ringB, &ctl.b_head, &ctl.b_tail, ~0ull, lane, id, got, bad);
-                bool onward = false;
-                if (STATS && n != 0u) {
-                    st_scat += 1;
-                    st_scat_l += n;
-                }
-                if (got) {
-                    const uint4 a = slotA[id], b = slotB[id], c = slotC[id];
-                    const f3 pos = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-                    f3 d = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-                    f3 rad = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
-                    uint32_t s = a.w, depth = b.w;
-                    // ---- the scatter phase of render_delta_kernel (cloudRadianceMaterials.cu:53-61) ----
-                    const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1u) : false);
-                    const NeeLoads nee = in_scattering_issue(sc, pos, d, chopped);
-                    c_il += 1;
-                    bool go = (MODE != 2);
-                    if (go) {
-                        d = new_direction(lds.cdf, lds.guide, s, d);
-                        depth++;
-                        if (depth == sc.max_depth) {
-                            c_cap += 1;
-                            go = false;
-                        }
-                    }
-                    rad = add3(rad, in_scattering_finish(sc, nee, pos));
-                    if (go) {
-                        slotA[id].w = s;
-                        slotB[id] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), depth);
-                        slotC[id] = make_uint4(__float_as_uint(rad.x), __float_as_uint(rad.y), __float_as_uint(rad.z), c.w);
-                        onward = true;
-                    } else {
-                        ba.frames[c.w] = make_float4(rad.x, rad.y, rad.z, 1.f);
-                        if (STATS) {
-                            iv_written += 1;
-                        }
-                        slotB[id].w = kXEmpty;
-                    }
-                }
-                if (n != 0u) {
-                    const uint32_t n_onward = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(onward));
-                    ended_paths += (int32_t)(n - n_onward);
-                    // a finished path's slot goes on as an empty one while some wave may still start samples
-                    const bool all_drained = x_load(&ctl.drained_waves) == (uint32_t)kXWaves;
-                    x_push(ringT, &ctl.t_tail, got && (onward || !all_drained), id, lane);
-                }
+            bool duty;
+            if (n_scatter_waves == 0u) {
+                // every wave does both: a full batch, or what is left once this wave has nothing else to do
+                duty = snap.b_pending >= 64u ||
+                       (snap.b_pending != 0u && drained && q_next == q_end && __builtin_amdgcn_ballot_w64(state == ST_MARCH) == 0ull);
+            } else {
+                duty = snap.b_pending >= 256u;   // the scatter waves are behind
+            }
+            if (duty) {
+                scatter_batch(snap);
             }
         }
 
-        // ---------------- (2) refill: lanes without a slot take one from the TRACK ring ----------------
+        // ---------------- (2) refill: lanes without a path adopt one from the TRACK ring ----------------
+        if (!drained && q_next == q_end && snap.no_jobs != 0u) {
+            drained = true;   // (nothing left to take, and this wave's own job is used up)
+        }
         {
             const uint64_t needy = __builtin_amdgcn_ballot_w64(state == ST_IDLE && slot == kXNoSlot);
-            if (needy != 0ull && x_load(&ctl.t_tail) != x_load(&ctl.t_head)) {
+            if (needy != 0ull && (snap.t_pending != 0u || snap.b_pending >= 64u)) {   // (a batch of step 1 may just have added some)
                 uint32_t id = 0;
                 bool got;
                 const uint32_t n = x_pop(ringT, &ctl.t_head, &ctl.t_tail, needy, lane, id, got, bad);
@@ -261,24 +338,35 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
                 }
                 if (got) {
                     slot = id;
-                    const uint4 b = slotB[id];
-                    if ((b.w & kXEmpty) == 0u) {
-                        const uint4 a = slotA[id];
-                        dir = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-                        seed = a.w;
-                        dda_begin(sc, dda, mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)), dir);
-                        state = ST_MARCH;
-                    }
+                    const uint4 a = slotA[id], b = slotB[id];
+                    dir = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+                    seed = a.w;
+                    dda_begin(sc, dda, mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)), dir);
+                    state = ST_MARCH;
                 }
             }
         }
-        // ---------------- (2b) lanes with an empty slot start a new sample (as render_delta_kernel regenerates) ----------------
+        // ---------------- (2b) new samples (as render_delta_kernel regenerates), in free slots ----------------
         {
+            const bool may_start = !(drained && q_next == q_end);
+            // lanes that still have nothing take a free slot, if this wave has samples to start
+            const uint64_t slotless = __builtin_amdgcn_ballot_w64(state == ST_IDLE && slot == kXNoSlot);
+            if (may_start && slotless != 0ull && snap.f_pending != 0u) {
+                uint32_t id = 0;
+                bool got;
+                x_pop(ringF, &ctl.f_head, &ctl.f_tail, slotless, lane, id, got, bad);
+                if (got) {
+                    slot = id;
+                }
+            }
             const bool empty = state == ST_IDLE && slot != kXNoSlot;
             const uint64_t idle = __builtin_amdgcn_ballot_w64(empty);
             const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-            if (n_idle != 0u && drained && q_next == q_end) {
-                // nothing left to start: the slots go out of circulation, the lanes can adopt queued paths
+            if (n_idle != 0u && !may_start) {
+                // nothing left to start here: the slots go to the waves that still start samples, or out of circulation
+                if (snap.drained_waves != (uint32_t)kXWaves) {
+                    x_push(ringF, &ctl.f_tail, empty, slot, lane);
+                }
                 if (empty) {
                     slot = kXNoSlot;
                 }
@@ -287,6 +375,9 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
                     uint32_t j = 0;
                     if (!take_job(ba, lane, q_cur, q_tried, j)) {
                         drained = true;
+                        if (lane == 0) {
+                            __hip_atomic_store(&ctl.no_jobs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     } else {
                         const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
                         job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
@@ -381,8 +472,9 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
                     st_march += 1;
                     st_march_l += (uint32_t)__builtin_popcountll(marching);
                 }
+                bool ended = false;
                 if (state == ST_MARCH) {
-                    bool ended = false, collide = false;
+                    bool collide = false;
                     float sigma_bar = 0.0f, sigma_low = 0.0f;
                     if (!cell_in_grid(sc, dda)) {
                         ended = true;
@@ -434,8 +526,8 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
                         }
                         state = ST_IDLE;   // (the slot stays with the lane, empty)
                     }
-                    ended_paths += (int32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ended));
                 }
+                ended_paths += (int32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ended));   // (wave-uniform: outside the branch)
                 if (--burst == 0u) {
                     break;
                 }
@@ -448,12 +540,7 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
         }
 
         // ---------------- (4) bookkeeping, exit ----------------
-        if (ended_paths != 0) {
-            if (lane == 0) {
-                __hip_atomic_fetch_add(&ctl.live, -ended_paths, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            ended_paths = 0;
-        }
+        flush_ended();
         if (drained && q_next == q_end) {
             if (!announced) {
                 announced = true;
@@ -462,12 +549,11 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
                 }
             }
             if (__builtin_amdgcn_ballot_w64(state == ST_MARCH) == 0ull) {
-                const bool all_drained = x_load(&ctl.drained_waves) == (uint32_t)kXWaves;
-                const int32_t live = (int32_t)x_load((const uint32_t *)&ctl.live);
-                if (all_drained && live == 0) {
+                // (the snapshot is from before this visit: a wave leaves one visit after the last path has gone)
+                if (snap.drained_waves == (uint32_t)kXWaves && snap.live == 0) {
                     break;
                 }
-                if (x_load(&ctl.b_tail) == x_load(&ctl.b_head) && x_load(&ctl.t_tail) == x_load(&ctl.t_head)) {
+                if (snap.b_pending == 0u && snap.t_pending == 0u) {
                     __builtin_amdgcn_s_sleep(8);   // the last paths are in other waves' lanes
                     if (STATS) {
                         st_spin += 1;
@@ -528,7 +614,7 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
 // Bytes of dynamic LDS for a pool of n_slots slots + the two rings.
 inline size_t delta_x_pool_bytes(uint32_t n_slots)
 {
-    return (size_t)n_slots * 48u + 2u * kXRing * sizeof(uint16_t);
+    return (size_t)n_slots * 48u + 3u * kXRing * sizeof(uint16_t);
 }
 
 hipError_t launch_render_delta_x(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream)
@@ -536,16 +622,7 @@ hipError_t launch_render_delta_x(const DevScene &sc, const BatchArgs &ba, Launch
     const dim3 grid(shape.blocks), block(kXThreads);
     const uint32_t n_slots = shape.pool_slots;
     const size_t dyn = delta_x_pool_bytes(n_slots);
-#define CT_X_LAUNCH(M, S)                                                                                                   \
-    do {                                                                                                                    \
-        static bool attr_set = false;                                                                                       \
-        if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute((const void *)render_delta_x_kernel<M, S>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)(160 * 1024));                                                                   \
-            attr_set = true;                                                                                                \
-        }                                                                                                                   \
-        hipLaunchKernelGGL((render_delta_x_kernel<M, S>), grid, block, dyn, stream, sc, ba, n_slots);                       \
-    } while (0)
+#define CT_X_LAUNCH(M, S) hipLaunchKernelGGL((render_delta_x_kernel<M, S>), grid, block, dyn, stream, sc, ba, n_slots, shape.scatter_waves)
     if (shape.stats) {
         switch (sc.mode) {
         case 0: CT_X_LAUNCH(0, true); break;
@@ -576,15 +653,28 @@ LaunchShape exchange_shape(int device)
     if (hipFuncGetAttributes(&fa, (const void *)render_delta_x_kernel<0, false>) == hipSuccess) {
         fixed = fa.sharedSizeBytes;
     }
-    const size_t room = 160 * 1024 - fixed - 2u * kXRing * sizeof(uint16_t);
+    const size_t room = 160 * 1024 - fixed - 3u * kXRing * sizeof(uint16_t);
     uint32_t slots = (uint32_t)(room / 48u);
-    slots = std::min(slots & ~63u, (uint32_t)kXThreads + kXRing);
+    slots = std::min(slots & ~1u, (uint32_t)kXThreads + kXRing);
     if (const char *e = getenv("CT_X_SLOTS")) {
         const int v = atoi(e);
         if (v >= kXThreads && (uint32_t)v <= slots) {
-            slots = (uint32_t)v & ~63u;
+            slots = (uint32_t)v & ~1u;
         }
     }
+    // more than 64 KiB of LDS per block in all: every instantiation is told how much dynamic LDS it may be launched with
+    const int dyn = (int)delta_x_pool_bytes(slots);
+    (void)hipFuncSetAttribute((const void *)render_delta_x_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_x_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_x_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_x_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_x_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_x_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipGetLastError();
     s.pool_slots = slots;
+    s.scatter_waves = 6;   // of the block's 16 (CT_X_SCATTER_WAVES; 0 = every wave does both)
+    if (const char *e = getenv("CT_X_SCATTER_WAVES")) {
+        s.scatter_waves = (uint32_t)std::min(kXWaves - 1, std::max(0, atoi(e)));
+    }
     return s;
 }

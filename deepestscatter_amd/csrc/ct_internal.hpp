@@ -74,6 +74,7 @@ struct LaunchShape {
     int threads;
     bool stats;   // launch the diagnostics build of the kernel (CT_STATS / CT_DEBUG_INVARIANTS at ct_create)
     uint32_t pool_slots = 0;   // exchange kernels (ct_exchange.hpp): slots of the block's path pool in LDS
+    uint32_t scatter_waves = 0; // ... and how many of a block's 16 waves only run scatter batches
 };
 
 // Evenly split job list (no locality information): point tasks, first launches.

@@ -52,11 +52,14 @@ def parity(estimator):
     return ok
 
 
-def timing(estimator, spp, steps, volume, size):
+def timing(estimator, spp, steps, volume, size, stats=False):
     import deepestscatter_amd as ds
     tex = ds.make_procedural_cloud(volume)
     out = {}
-    for name, env in (("per_lane", {"CT_EXCHANGE": "0", "CT_CONTINUATION": "0"}), ("exchange", {"CT_EXCHANGE": "1"})):
+    variants = [("per_lane", {"CT_EXCHANGE": "0", "CT_CONTINUATION": "0"}), ("exchange", {"CT_EXCHANGE": "1"})]
+    if stats:
+        variants = [("exchange_stats", {"CT_EXCHANGE": "1", "CT_STATS": "1"})]
+    for name, env in variants:
         tr = make(tex, env, width=size, height=size, estimator=estimator)
         tr.render_accumulate(1, 32)
         first = 33
@@ -68,7 +71,13 @@ def timing(estimator, spp, steps, volume, size):
         rms, ams, launches = tr.kernel_time()
         out[name] = {"ms_per_step": dt * 1e3, "Msamples_per_s": size * size * spp / dt / 1e6, "mean_checksum": float(tr.mean().astype(np.float64).sum())}
         print(name, json.dumps(out[name]), flush=True)
+        if stats:
+            r = tr.debug_stats()["raw"]
+            print("stats: regen phases %d lanes/phase %.1f | tracking visits %d lanes/visit %.1f | scatter batches %d lanes/batch %.1f | adoptions %d lanes/adoption %.1f | idle spins %d | watchdog %d"
+                  % (r[0], r[1] / max(r[0], 1), r[2], r[3] / max(r[2], 1), r[4], r[5] / max(r[4], 1), r[33], r[34] / max(r[33], 1), r[35], r[63]), flush=True)
         tr.close()
+    if stats:
+        return out
     assert out["per_lane"]["mean_checksum"] == out["exchange"]["mean_checksum"], "the two kernels disagree"
     print("exchange_speedup", out["exchange"]["Msamples_per_s"] / out["per_lane"]["Msamples_per_s"])
     return out
@@ -83,8 +92,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--stats", action="store_true", help="timing leg: only the exchange kernel's diagnostics build, print its phase statistics")
     a = ap.parse_args()
     if not a.skip_parity and not parity(a.estimator):
         sys.exit(1)
     if not a.skip_timing:
-        timing(a.estimator, a.spp, a.steps, a.volume, a.size)
+        timing(a.estimator, a.spp, a.steps, a.volume, a.size, a.stats)

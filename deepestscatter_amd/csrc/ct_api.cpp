@@ -122,7 +122,7 @@ struct CtHandle_ {
     LaunchShape shape{ 1024, 256, false };
     // CT_EXCHANGE=1: the estimator kernels with a block-wide exchange of paths between waves (ct_exchange.hpp) render the
     // batches whose job order is tuned; the cost-measuring launch of a pose keeps the per-lane kernels
-    bool exchange = false;
+    int exchange = 0;                  // 0 per-lane kernels, 1 block-wide exchange, 2 exchange within a wave
     LaunchShape xshape{ 256, 1024, false };
     uint32_t subframes = 0;
     double render_ms = 0, accum_ms = 0;
@@ -326,10 +326,10 @@ static int create_impl(const CtScene *s, CtHandle h)
     }
     h->shape.stats = getenv("CT_STATS") != nullptr || h->debug_invariants;
     if (const char *e = getenv("CT_EXCHANGE")) {
-        h->exchange = atoi(e) != 0 && s->estimator == CT_EST_DELTA;
+        h->exchange = s->estimator == CT_EST_DELTA ? std::min(2, std::max(0, atoi(e))) : 0;
     }
     if (h->exchange) {
-        h->xshape = exchange_shape(s->device);
+        h->xshape = h->exchange == 2 ? wave_exchange_shape(s->device) : exchange_shape(s->device);
         h->xshape.stats = h->shape.stats;
     }
 
@@ -1245,7 +1245,11 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     } else {
         if (h->n_jobs != 0 || ba.cont_in) {
             if (h->exchange && !ba.cost && !ba.cont_in && !ba.cont_out && h->scene.estimator == CT_EST_DELTA) {
-                HIPCHK(h, launch_render_delta_x(h->dev, ba, h->xshape, h->stream));
+                if (h->exchange == 2) {
+                    HIPCHK(h, launch_render_delta_w(h->dev, ba, h->xshape, h->stream));
+                } else {
+                    HIPCHK(h, launch_render_delta_x(h->dev, ba, h->xshape, h->stream));
+                }
             } else if (h->scene.estimator == CT_EST_DELTA) {
                 HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
             } else {

@@ -678,3 +678,454 @@ LaunchShape exchange_shape(int device)
     }
     return s;
 }
+
+// =============================================================================================================================
+// render_delta_w_kernel: the same regrouping of paths by phase, but WITHIN a wave -- no atomics, no fences, no other wave.
+//
+// The block-wide exchange above pays for its generality: per scheduler visit a snapshot of the control words, a compare-and-swap
+// per pop, an atomic add per push, three rings -- +25 % instructions in all instead of fewer, and lanes that wait for whichever
+// wave comes round to the scatter batch (profiles/r03c).  A wave does not need the other waves to fill its lanes; it needs more
+// paths than lanes.  Here every wave owns S slots of the block's pool (S = 112 with 16 waves and the 84 KiB the tables leave) and
+// three private lists of slot indices, kept as stacks whose heights live in SGPRs:
+//     BOUNCE  paths that collided and wait for the scatter phase      TRACK  scattered paths that wait for a lane
+//     FREE    slots without a path
+// A tracking visit's collided lanes push their slot on BOUNCE (position = height + the lane's rank in the ballot) and adopt the
+// top entries of TRACK; when BOUNCE holds 64 entries the wave runs the scatter phase for them on all 64 lanes -- whatever those
+// lanes hold as tracking state stays in their registers -- and pushes them on TRACK.  Everything is wave-synchronous: LDS executes a wave's
+// instructions in order, so a list entry written by one lane is read by another without any synchronisation instruction.
+// Same slots (A, B, C), same arithmetic per path, same results as render_delta_kernel bit for bit.
+// =============================================================================================================================
+constexpr uint32_t kWListCap = 128;   // entries per private list (>= slots per wave)
+
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(kXThreads) void render_delta_w_kernel(DevScene sc, BatchArgs ba, uint32_t slots_per_wave)
+{
+    __shared__ MieLds lds;
+    __shared__ uint32_t maj_words[kMajCellsMax / 4];
+    __shared__ uint8_t lds_codes[kMajCellsMax / 4];
+    __shared__ float2 sigma_table[256];
+    extern __shared__ uint4 x_pool[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_slots = slots_per_wave * (uint32_t)kXWaves;
+    uint4 *const slotA = x_pool + wave * slots_per_wave, *const slotB = slotA + n_slots, *const slotC = slotB + n_slots;
+    uint8_t *const lists = (uint8_t *)(x_pool + 3u * n_slots) + wave * 3u * kWListCap;
+    uint8_t *const listB = lists, *const listT = lists + kWListCap, *const listF = lists + 2u * kWListCap;
+    {
+        const uint32_t words = ((uint32_t)(sc.mc_gx * sc.mc_gy * sc.mc_gz) + 3u) >> 2;
+        const uint32_t *src = (const uint32_t *)sc.maj_cells, *srcc = (const uint32_t *)sc.maj_codes;
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
+            maj_words[i] = src[i];
+            const uint32_t w = srcc[i];
+            lds_codes[i] = (uint8_t)((w & 3u) | ((w >> 6) & 0xcu) | ((w >> 12) & 0x30u) | ((w >> 18) & 0xc0u));
+        }
+        if (threadIdx.x < 256u) {
+            const float sb = ((float)threadIdx.x * (1.0f / 255.0f)) * sc.density_multiplier;
+            sigma_table[threadIdx.x] = make_float2(sb, 1.0f / sb);
+        }
+        // the wave's slots beyond its lanes' own start on its FREE list
+        for (uint32_t i = lane; i + 64u < slots_per_wave; i += 64u) {
+            listF[i] = (uint8_t)(64u + i);
+        }
+    }
+    const uint8_t *lds_maj = (const uint8_t *)maj_words;
+    load_tables(sc, lds);   // (ends with the block's barrier)
+
+    uint32_t nb = 0, nt = 0, nf = slots_per_wave - 64u;   // heights of the three lists (wave-uniform)
+    f3 dir = mk3(0, 0, 1);
+    Dda dda{};
+    uint32_t seed = 0, slot = lane;    // this lane's slot (index within the wave's region) or kXNoSlot
+    int state = ST_IDLE;
+
+    uint32_t q_next = 0, q_end = 0, job_g = 0, job_s0 = 0;
+    uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
+    bool drained = false;
+    uint32_t c_dl = 0, c_il = 0, c_cap = 0;
+    uint32_t st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0, st_regen = 0, st_regen_l = 0, st_adopt = 0, st_adopt_l = 0;
+    uint32_t iv_dealt = 0, iv_written = 0;
+
+    const unsigned long long t_start = wall_clock64();
+    uint32_t visit = 0;
+    for (;;) {
+        visit += 1;
+        if ((visit & 1023u) == 0u && wall_clock64() - t_start > kXWatchdogTicks) {
+            if (lane == 0) {
+                atomicAdd(&ba.stats[63], 1ull);   // watchdog (tests assert 0): give up rather than hang the GPU
+            }
+            break;
+        }
+        const uint64_t marching0 = __builtin_amdgcn_ballot_w64(state == ST_MARCH);
+        const bool may_start = !(drained && q_next == q_end);
+        // ---------------- (1) the scatter phase for up to 64 collided paths ----------------
+        // (a partial batch: when the wave has nothing else to do, or when a quarter of its lanes can get neither a queued path
+        // nor a new sample while half a batch waits here)
+        const uint32_t lanes_free = 64u - (uint32_t)__builtin_popcountll(marching0);
+        if (nb >= 64u || (nb != 0u && nt == 0u && (marching0 == 0ull || (nb >= 32u && lanes_free >= 16u && (nf == 0u || !may_start))))) {
+            const uint32_t n = min(nb, 64u);
+            nb -= n;
+            bool onward = false, finished = false;
+            uint32_t id = 0;
+            if (STATS) {
+                st_scat += 1;
+                st_scat_l += n;
+            }
+            if (lane < n) {
+                id = listB[nb + lane];
+                const uint4 a = slotA[id], b = slotB[id], c = slotC[id];
+                const f3 pos = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+                f3 d = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+                f3 rad = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+                uint32_t s = a.w, depth = b.w;
+                // ---- the scatter phase of render_delta_kernel (cloudRadianceMaterials.cu:53-61) ----
+                const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1u) : false);
+                const NeeLoads nee = in_scattering_issue(sc, pos, d, chopped);
+                c_il += 1;
+                bool go = (MODE != 2);
+                if (go) {
+                    d = new_direction(lds.cdf, lds.guide, s, d);
+                    depth++;
+                    if (depth == sc.max_depth) {
+                        c_cap += 1;
+                        go = false;
+                    }
+                }
+                rad = add3(rad, in_scattering_finish(sc, nee, pos));
+                if (go) {
+                    slotA[id].w = s;
+                    slotB[id] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), depth);
+                    slotC[id] = make_uint4(__float_as_uint(rad.x), __float_as_uint(rad.y), __float_as_uint(rad.z), c.w);
+                    onward = true;
+                } else {
+                    ba.frames[c.w] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                    if (STATS) {
+                        iv_written += 1;
+                    }
+                    finished = true;
+                }
+            }
+            const uint64_t on = __builtin_amdgcn_ballot_w64(onward), fin = __builtin_amdgcn_ballot_w64(finished);
+            if (onward) {
+                listT[nt + lane_rank(on)] = (uint8_t)id;
+            }
+            if (finished) {
+                listF[nf + lane_rank(fin)] = (uint8_t)id;
+            }
+            nt += (uint32_t)__builtin_popcountll(on);
+            nf += (uint32_t)__builtin_popcountll(fin);
+        }
+
+        // ---------------- (2) lanes without a path adopt the top of TRACK ----------------
+        {
+            const bool want = state == ST_IDLE && slot == kXNoSlot;
+            const uint64_t needy = __builtin_amdgcn_ballot_w64(want);
+            if (needy != 0ull && nt != 0u) {
+                const uint32_t k = min((uint32_t)__builtin_popcountll(needy), nt);
+                nt -= k;
+                const uint32_t rank = lane_rank(needy);
+                if (STATS) {
+                    st_adopt += 1;
+                    st_adopt_l += k;
+                }
+                if (want && rank < k) {
+                    const uint32_t id = listT[nt + rank];
+                    slot = id;
+                    const uint4 a = slotA[id], b = slotB[id];
+                    dir = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+                    seed = a.w;
+                    dda_begin(sc, dda, mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)), dir);
+                    state = ST_MARCH;
+                }
+            }
+        }
+        // ---------------- (2b) new samples in free slots (as render_delta_kernel regenerates) ----------------
+        {
+            if (may_start) {
+                // lanes that still have nothing take a free slot
+                const bool want = state == ST_IDLE && slot == kXNoSlot;
+                const uint64_t needy = __builtin_amdgcn_ballot_w64(want);
+                if (needy != 0ull && nf != 0u) {
+                    const uint32_t k = min((uint32_t)__builtin_popcountll(needy), nf);
+                    nf -= k;
+                    const uint32_t rank = lane_rank(needy);
+                    if (want && rank < k) {
+                        slot = listF[nf + rank];
+                    }
+                }
+            }
+            const bool empty = state == ST_IDLE && slot != kXNoSlot;
+            const uint64_t idle = __builtin_amdgcn_ballot_w64(empty);
+            const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+            if (n_idle != 0u && !may_start) {
+                if (empty) {
+                    slot = kXNoSlot;   // nothing left to start: the lane is free for a queued path, the slot goes out of use
+                }
+            } else if (n_idle >= sc.regen_min || n_idle == 64u || (n_idle != 0u && __builtin_amdgcn_ballot_w64(state == ST_MARCH) == 0ull)) {
+                if (q_next == q_end) {
+                    uint32_t j = 0;
+                    if (!take_job(ba, lane, q_cur, q_tried, j)) {
+                        drained = true;
+                    } else {
+                        const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
+                        job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
+                        job_s0 = sub & 0xffffu;
+                        q_next = 0;
+                        q_end = (job_s0 < ba.S ? min(sub >> 16, ba.S - job_s0) : 0u) * 64u;
+                    }
+                }
+                if (q_next != q_end) {
+                    const uint32_t avail = q_end - q_next;
+                    if (STATS) {
+                        st_regen += 1;
+                        st_regen_l += min(n_idle, avail);
+                    }
+                    const uint32_t rank = lane_rank(idle);
+                    const bool take = empty && rank < avail;
+                    const uint32_t q = q_next + rank;
+                    q_next += min(n_idle, avail);
+                    if (take) {
+                        const uint32_t s = job_s0 + (q >> 6), l = q & 63u;
+                        const uint32_t g = job_g;
+                        const uint32_t pixel = ba.pixels[g * 64u + l];
+                        if (pixel != 0xffffffffu) {
+                            if (STATS) {
+                                iv_dealt += 1;
+                            }
+                            const float4 p0 = ba.primary[2 * (size_t)pixel];
+                            const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
+                            const uint32_t out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + (g * 64u + l) : pixel;
+                            const f3 pos = mk3(p0.x, p0.y, p0.z);
+                            const bool hit = p0.w != 0.f;
+                            dir = mk3(p1.x, p1.y, p1.z);
+                            seed = tea4(__float_as_uint(p1.w), ba.first_subframe + s);
+                            uint32_t depth = 0;
+                            if (MODE == 1) {
+                                dir = new_direction(lds.cdf, lds.guide, seed, dir);
+                            }
+                            bool go = hit && in_box(sc, pos);
+                            if (MODE != 2 && go) {
+                                depth = 1;
+                                if (depth == sc.max_depth) {
+                                    c_cap += 1;
+                                    go = false;
+                                }
+                            }
+                            if (go) {
+                                if (MODE != 1 && ba.advance) {
+                                    const float4 a0 = ba.advance[4 * (size_t)pixel], a1 = ba.advance[4 * (size_t)pixel + 1];
+                                    const float4 a2 = ba.advance[4 * (size_t)pixel + 2], a3 = ba.advance[4 * (size_t)pixel + 3];
+                                    dda.org = mk3(a0.x, a0.y, a0.z);
+                                    dda.t = a0.w;
+                                    dda.tmax = mk3(a1.x, a1.y, a1.z);
+                                    dda.bx = __float_as_int(a1.w);
+                                    dda.tdelta = mk3(a2.x, a2.y, a2.z);
+                                    dda.by = __float_as_int(a2.w);
+                                    dda.bz = __float_as_int(a3.x);
+                                } else {
+                                    dda_begin(sc, dda, pos, dir);
+                                }
+                                slotB[slot] = make_uint4(__float_as_uint(dir.x), __float_as_uint(dir.y), __float_as_uint(dir.z), depth);
+                                slotC[slot] = make_uint4(0u, 0u, 0u, out_idx);   // radiance (0, 0, 0)
+                                state = ST_MARCH;
+                            } else {
+                                ba.frames[out_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
+                                if (STATS) {
+                                    iv_written += 1;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---------------- (3) tracking visits (render_delta_kernel's, for the lanes in flight) ----------------
+        bool collided = false;
+        {
+            uint32_t burst = sc.march_burst;
+            for (;;) {
+                const uint64_t marching = __builtin_amdgcn_ballot_w64(state == ST_MARCH);
+                if (marching == 0ull) {
+                    break;
+                }
+                if (STATS) {
+                    st_march += 1;
+                    st_march_l += (uint32_t)__builtin_popcountll(marching);
+                }
+                if (state == ST_MARCH) {
+                    bool ended = false, collide = false;
+                    float sigma_bar = 0.0f, sigma_low = 0.0f;
+                    if (!cell_in_grid(sc, dda)) {
+                        ended = true;
+                    } else {
+                        const uint32_t ci = cell_index(sc, dda);
+                        const uint32_t M = lds_maj[ci];
+                        if (M != 0u) {
+                            const uint32_t q = ((uint32_t)lds_codes[ci >> 2] >> ((ci & 3u) * 2u)) & 3u;
+                            sigma_low = sigma_table[(q * M) >> 2].x;
+                            const float2 sb = sigma_table[M];
+                            sigma_bar = sb.x;
+                            const float u = u24_to_float(lcg24(seed));
+                            const float dt = -logf_above_one(1.0f - u) * sb.y;
+                            const float t_exit = fminf(fminf(dda.tmax.x, dda.tmax.y), dda.tmax.z);
+                            if (dda.t + dt < t_exit) {
+                                dda.t = dda.t + dt;
+                                collide = true;
+                            }
+                        }
+                        if (!collide) {
+                            dda_cross(dda, dir);
+                        }
+                    }
+                    if (collide) {
+                        const f3 p = mk3(fmaf(dir.x, dda.t, dda.org.x), fmaf(dir.y, dda.t, dda.org.y), fmaf(dir.z, dda.t, dda.org.z));
+                        const float z = u24_to_float(lcg24(seed));
+                        bool real = z * sigma_bar < sigma_low;
+                        if (!real) {
+                            uint32_t meta_unused;
+                            const uint2 cell = fetch_cell_in_grid(sc, sc.dbricks, p, meta_unused);
+                            c_dl += 1;
+                            real = z * sigma_bar < filter_at(sc, cell, p) * sc.density_multiplier;
+                        }
+                        if (real) {
+                            if (in_box(sc, p)) {
+                                slotA[slot] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), seed);
+                                collided = true;
+                                state = ST_IDLE;
+                            } else {
+                                ended = true;
+                            }
+                        }
+                    }
+                    if (ended) {
+                        const uint4 c = slotC[slot];
+                        ba.frames[c.w] = make_float4(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), 1.f);
+                        if (STATS) {
+                            iv_written += 1;
+                        }
+                        state = ST_IDLE;   // (the slot stays with the lane, empty)
+                    }
+                }
+                if (--burst == 0u) {
+                    break;
+                }
+            }
+        }
+        // the collided paths wait on BOUNCE; their lanes are free for another path
+        {
+            const uint64_t cm = __builtin_amdgcn_ballot_w64(collided);
+            if (collided) {
+                listB[nb + lane_rank(cm)] = (uint8_t)slot;
+                slot = kXNoSlot;
+            }
+            nb += (uint32_t)__builtin_popcountll(cm);
+        }
+
+        // ---------------- (4) exit: no job left, no path in a lane or on a list ----------------
+        if (drained && q_next == q_end && nb == 0u && nt == 0u && __builtin_amdgcn_ballot_w64(state == ST_MARCH) == 0ull) {
+            break;
+        }
+    }
+
+    uint32_t vals[3] = { c_dl, c_il, c_cap };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        uint32_t v = vals[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            v += __shfl_xor(v, off);
+        }
+        vals[i] = v;
+    }
+    if (STATS) {
+        uint32_t sv[2] = { iv_dealt, iv_written };
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            uint32_t v = sv[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                v += __shfl_xor(v, off);
+            }
+            sv[i] = v;
+        }
+        if (lane == 0) {
+            atomicAdd(&ba.stats[0], (unsigned long long)st_regen);
+            atomicAdd(&ba.stats[1], (unsigned long long)st_regen_l);
+            atomicAdd(&ba.stats[2], (unsigned long long)st_march);
+            atomicAdd(&ba.stats[3], (unsigned long long)st_march_l);
+            atomicAdd(&ba.stats[4], (unsigned long long)st_scat);
+            atomicAdd(&ba.stats[5], (unsigned long long)st_scat_l);
+            atomicAdd(&ba.stats[33], (unsigned long long)st_adopt);
+            atomicAdd(&ba.stats[34], (unsigned long long)st_adopt_l);
+            atomicAdd(&ba.stats[64], (unsigned long long)sv[0]);
+            atomicAdd(&ba.stats[66], (unsigned long long)sv[1]);
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&ba.counters[2], (unsigned long long)vals[0]);
+        atomicAdd(&ba.counters[3], (unsigned long long)vals[1]);
+        atomicAdd(&ba.counters[4], (unsigned long long)vals[1]);
+        atomicAdd(&ba.counters[5], (unsigned long long)vals[2]);
+        atomicAdd(&ba.counters[6], (unsigned long long)vals[0]);
+        atomicAdd(&ba.counters[7], (unsigned long long)vals[1]);
+    }
+}
+
+inline size_t delta_w_pool_bytes(uint32_t slots_per_wave)
+{
+    return (size_t)slots_per_wave * kXWaves * 48u + (size_t)kXWaves * 3u * kWListCap;
+}
+
+hipError_t launch_render_delta_w(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream)
+{
+    const dim3 grid(shape.blocks), block(kXThreads);
+    const uint32_t spw = shape.pool_slots;
+    const size_t dyn = delta_w_pool_bytes(spw);
+#define CT_W_LAUNCH(M, S) hipLaunchKernelGGL((render_delta_w_kernel<M, S>), grid, block, dyn, stream, sc, ba, spw)
+    if (shape.stats) {
+        switch (sc.mode) {
+        case 0: CT_W_LAUNCH(0, true); break;
+        case 1: CT_W_LAUNCH(1, true); break;
+        default: CT_W_LAUNCH(2, true); break;
+        }
+    } else {
+        switch (sc.mode) {
+        case 0: CT_W_LAUNCH(0, false); break;
+        case 1: CT_W_LAUNCH(1, false); break;
+        default: CT_W_LAUNCH(2, false); break;
+        }
+    }
+#undef CT_W_LAUNCH
+    return hipGetLastError();
+}
+
+// One block per CU; every wave gets an equal share of what the tables leave of the CU's 160 KiB.
+LaunchShape wave_exchange_shape(int device)
+{
+    LaunchShape s{ 256, kXThreads, false };
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+        s.blocks = prop.multiProcessorCount;
+    }
+    hipFuncAttributes fa{};
+    size_t fixed = 80 * 1024;
+    if (hipFuncGetAttributes(&fa, (const void *)render_delta_w_kernel<0, false>) == hipSuccess) {
+        fixed = fa.sharedSizeBytes;
+    }
+    const size_t room = 160 * 1024 - fixed - (size_t)kXWaves * 3u * kWListCap;
+    uint32_t spw = std::min((uint32_t)(room / (48u * kXWaves)), kWListCap - 1u);
+    if (const char *e = getenv("CT_X_SLOTS")) {   // per wave here
+        const int v = atoi(e);
+        if (v >= 64 && (uint32_t)v <= spw) {
+            spw = (uint32_t)v;
+        }
+    }
+    s.pool_slots = spw;
+    const int dyn = (int)delta_w_pool_bytes(spw);
+    (void)hipFuncSetAttribute((const void *)render_delta_w_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_w_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_w_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_w_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_w_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)render_delta_w_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipGetLastError();
+    return s;
+}

@@ -156,5 +156,7 @@ LaunchShape persistent_shape(int device, bool delta);
 // The estimators with a block-wide exchange of paths between waves (ct_exchange.hpp): one 1024-thread block per CU.
 LaunchShape exchange_shape(int device);
 hipError_t launch_render_delta_x(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
+LaunchShape wave_exchange_shape(int device);   // the exchange within a wave (render_delta_w_kernel): pool_slots = slots per wave
+hipError_t launch_render_delta_w(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 
 } // namespace ct

@@ -13,6 +13,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 
+XMODE = os.environ.get("CT_EXCHANGE", "1")   # 1 = block-wide exchange, 2 = exchange within a wave
+
 
 def make(tex, env, **kw):
     import deepestscatter_amd as ds
@@ -34,7 +36,7 @@ def parity(estimator):
     ok = True
     for n, size, spp, mode in [(32, 48, 8, 0), (48, 64, 6, 1), (40, 64, 8, 2), (96, 128, 24, 0)]:
         tex = ds.make_procedural_cloud(n)
-        tr = make(tex, {"CT_EXCHANGE": "1", "CT_STATS": "1"}, width=size, height=size, mode=mode, estimator=estimator)
+        tr = make(tex, {"CT_EXCHANGE": XMODE, "CT_STATS": "1"}, width=size, height=size, mode=mode, estimator=estimator)
         tr.render_accumulate(1, spp)            # first 32 subframes of a pose: the cost-measuring launch (per-lane kernel)
         tr.render_accumulate(spp + 1, spp)      # exchange kernel
         tr.render_accumulate(2 * spp + 1, 40)   # exchange kernel, long enough to cycle the rings
@@ -56,9 +58,9 @@ def timing(estimator, spp, steps, volume, size, stats=False):
     import deepestscatter_amd as ds
     tex = ds.make_procedural_cloud(volume)
     out = {}
-    variants = [("per_lane", {"CT_EXCHANGE": "0", "CT_CONTINUATION": "0"}), ("exchange", {"CT_EXCHANGE": "1"})]
+    variants = [("per_lane", {"CT_EXCHANGE": "0", "CT_CONTINUATION": "0"}), ("exchange", {"CT_EXCHANGE": XMODE})]
     if stats:
-        variants = [("exchange_stats", {"CT_EXCHANGE": "1", "CT_STATS": "1"})]
+        variants = [("exchange_stats", {"CT_EXCHANGE": XMODE, "CT_STATS": "1"})]
     for name, env in variants:
         tr = make(tex, env, width=size, height=size, estimator=estimator)
         tr.render_accumulate(1, 32)

@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        tag = "exchange" if "render_delta_x" in k else ("per_lane" if "render_delta_kernel" in k else None)
+        tag = "exchange" if ("render_delta_x" in k or "render_delta_w" in k) else ("per_lane" if "render_delta_kernel" in k else None)
         if tag:
             agg[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for tag in ("per_lane", "exchange"):

@@ -265,6 +265,11 @@ class CloudTracer:
         check(self.L.ct_tonemap(self.h, exposure, _p(screen), C.byref(avg)), self.h)
         return screen, float(avg.value)
 
+    def tonemap_async(self, exposure: float = 0.4):
+        """ct_tonemap_async: the display update enqueued behind the batches in flight; the screen stays on the device
+        (download(CT_BUF_SCREEN) after synchronize())."""
+        check(self.L.ct_tonemap_async(self.h, exposure), self.h)
+
     def is_converged(self):
         ok, bad = C.c_int32(0), C.c_uint64(0)
         check(self.L.ct_is_converged(self.h, C.byref(ok), C.byref(bad)), self.h)

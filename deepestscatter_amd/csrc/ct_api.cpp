@@ -43,33 +43,44 @@ struct CtHandle_ {
     uint16_t *d_guide = nullptr;
     float4 *d_frame = nullptr, *d_mean = nullptr, *d_m2 = nullptr;
     uchar4 *d_screen = nullptr;
-    // Batches enqueued with ct_render_accumulate_async form a pipeline on the handle's stream:
-    //     R1  R2 A1  R3 A2  ...  (flush:) Rf An
-    // The estimator launch R(k) of the MARCH estimator does not run its surviving paths to their end when
-    // its job list is empty: it suspends them (BatchArgs::cont_out) and R(k+1) resumes them first, so no
-    // launch ends with a tail of waves that carry a few long paths each.  A(k), the accumulate kernel
-    // of batch k, therefore follows R(k+1) (or the flush launch Rf, which only resumes).  Two slots
-    // alternate: a slot owns the half of the per-sample scratch a batch writes ([S][stride] compact or
-    // [S][H][W] for the simple kernel), its queue counters, its buffer of suspended paths and its events.
+    // Batches enqueued with ct_render_accumulate_async form a pipeline on the handle's stream (M = max_age):
+    //     R1  R2 .. R(1+M) A1  R(2+M) A2  ...  (flush:) Rf A(n-M+1) .. An
+    // The estimator launch R(k) does not run its surviving paths to their end when its job list is empty: it suspends
+    // them (BatchArgs::cont_out) and R(k+1) resumes them first, so no launch ends with a tail of waves that carry a few
+    // long paths each.  A path may be suspended M times, so batch k is complete once R(k+M) has run, and A(k), its
+    // accumulate kernel, follows that launch (or the flush launch Rf, which only resumes and runs everything to its end).
+    // The per-sample scratch is a ring of n_regions = M + 1 regions ([S][stride] compact, or [S][H][W] for the simple
+    // kernel): batch k writes region k mod n_regions, which A(k - n_regions) has long left.  M = 1 (two regions) is
+    // round 2's scheme and what long batches use -- a launch of 20 ms outlasts the longest path (2000 bounces, ~10 ms);
+    // short batches (the reference renders 10 subframes per display update, Camera.cpp:189) get more regions, so that a
+    // launch never has to wait for a path that an earlier one handed to it.
+    // A slot owns a region, its queue counters and its events; the suspended paths alternate between two buffers.
+    static constexpr int kMaxRegions = 16;
     struct Slot {
         uint32_t *queue = nullptr;
-        uint32_t *cont = nullptr;          // suspended paths written by this slot's launch
         hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_done = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr;
         bool pending = false;              // launched, kernel times not booked yet
         bool accumulated = false;          // its accumulate kernel has been enqueued (ev_acc0/1 valid)
         bool awaits_accumulate = false;    // launched with suspension: A(k) is still to be enqueued
-        bool suspended = false;            // launched with suspension, counter not read yet
         uint32_t first = 0, S = 0;
     };
-    Slot slots[2];
+    Slot slots[kMaxRegions];
+    int n_regions = 2;                     // regions of the scratch in use
     int next_slot = 0;
-    float4 *d_frames_all = nullptr;        // both halves of the per-sample scratch
-    size_t slot_capacity = 0;              // float4 per half
-    uint32_t *d_cont_count = nullptr;      // [2] entries in slots[i].cont, [2] = resume cursor
-    size_t cont_capacity = 0;              // entries per slot
+    std::vector<int> waiting;              // slots whose batch awaits its accumulate kernel, oldest first
+    uint32_t *cont[2] = { nullptr, nullptr }; // suspended paths: launch k writes cont[k & 1], launch k+1 reads it
+    uint64_t launch_no = 0;                // estimator launches enqueued so far
+    bool cont_live = false;                // the last launch may have suspended paths: the next one resumes them
+    float4 *d_frames_all = nullptr;        // the whole per-sample scratch
+    size_t frames_total = 0;               // float4 allocated
+    size_t slot_capacity = 0;              // float4 per region
+    uint32_t layout_S = 0;                 // batch size the regions were laid out for
+    uint32_t *d_cont_count = nullptr;      // [2] entries in cont[i], [2] = resume cursor
+    unsigned long long *d_cont_total = nullptr; // paths handed from one launch to the next so far (ct_debug_suspended)
+    size_t cont_capacity = 0;              // entries per buffer
     hipEvent_t ev_flush0 = nullptr, ev_flush1 = nullptr;
     bool continuation = true;              // CT_CONTINUATION=0: async batches run every path to its end
-    uint64_t suspended_total = 0;          // paths handed from one launch to the next so far (ct_debug_suspended)
+    int max_age_override = 0;              // CT_MAX_AGE=n: n + 1 regions whatever the batch size (0 = by batch duration)
     // work queue of the persistent kernel (rebuilt when the camera moves)
     float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
     float4 *d_advance = nullptr;      // per pixel: pre-walked prefix of the primary march (MARCH estimator)
@@ -268,7 +279,7 @@ static void release(CtHandle h)
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->slots[0].queue, h->slots[1].queue, h->slots[0].cont, h->slots[1].cont, h->d_cont_count, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
         if (p) {
@@ -281,6 +292,9 @@ static void release(CtHandle h)
         }
     }
     for (auto &sl : h->slots) {
+        if (sl.queue) {
+            hipFree(sl.queue);
+        }
         for (hipEvent_t e : { sl.ev_in, sl.ev_start, sl.ev_done, sl.ev_acc0, sl.ev_acc1 }) {
             if (e) {
                 hipEventDestroy(e);
@@ -738,8 +752,15 @@ static int create_impl(const CtScene *s, CtHandle h)
     if (h->exchange) {
         h->continuation = false;   // (the exchange kernels run every path to its end)
     }
+    if (const char *e = getenv("CT_MAX_AGE")) {
+        h->max_age_override = std::min(CtHandle_::kMaxRegions - 1, std::max(0, atoi(e)));
+    }
+    HIPCHK(h, dmalloc(&h->d_cont_total, 1));
+    HIPCHK(h, hipMemsetAsync(h->d_cont_total, 0, sizeof(unsigned long long), h->stream));
+    for (auto &c : h->cont) {
+        HIPCHK(h, dmalloc(&c, h->cont_capacity * (s->estimator == CT_EST_DELTA ? kContWordsDelta : kContWords)));
+    }
     for (auto &sl : h->slots) {
-        HIPCHK(h, dmalloc(&sl.cont, h->cont_capacity * (s->estimator == CT_EST_DELTA ? kContWordsDelta : kContWords)));
         HIPCHK(h, dmalloc(&sl.queue, kQueueWords));
         for (hipEvent_t *e : { &sl.ev_in, &sl.ev_start, &sl.ev_done, &sl.ev_acc0, &sl.ev_acc1 }) {
             HIPCHK(h, hipEventCreate(e));
@@ -1105,27 +1126,76 @@ static size_t frame_stride(CtHandle h)
     return (size_t)h->n_groups * 64;
 }
 
-// Both halves of the per-sample scratch, each large enough for a batch of S subframes.
-static int ensure_frames(CtHandle h, uint32_t S)
+// How many regions a batch of S subframes should have: enough launches between a batch and its accumulate kernel that
+// no path of it is still running -- a path needs up to ~10 ms (2000 bounces) of running time, a launch lasts about as long
+// as its samples take at ~3 Gsamples/s -- but never more than the budget holds.
+static int wanted_regions(CtHandle h, uint32_t S, uint64_t budget_float4)
+{
+    int r;
+    if (h->max_age_override > 0) {
+        r = h->max_age_override + 1;
+    } else {
+        const double est_ms = std::max(0.05, (double)S * (double)std::max<uint64_t>(h->hit_pixels, 1) / 3.0e6);
+        r = 1 + (int)std::ceil(15.0 / est_ms);
+    }
+    const uint64_t need = std::max<uint64_t>((uint64_t)S * frame_stride(h), 1);
+    r = (int)std::min<uint64_t>((uint64_t)r, std::max<uint64_t>(budget_float4 / need, 2));
+    return std::min(CtHandle_::kMaxRegions, std::max(2, r));
+}
+
+static uint64_t scratch_slot_bytes()
+{
+    // CT_SCRATCH_GIB sets the size of one of the two regions a long batch uses.  Default 16: the 1024-spp job of a 1024^2
+    // frame is then ONE launch, 14 GB, instead of two of 512 -- a launch costs a few ms besides its samples -- and 28 GB of
+    // scratch are a tenth of this GPU's memory.  Allocated as needed; a device that cannot give that much gets less (below).
+    uint64_t slot_bytes = 16ull << 30;
+    if (const char *e = getenv("CT_SCRATCH_GIB")) {
+        slot_bytes = (uint64_t)std::min(64, std::max(1, atoi(e))) << 30;
+    }
+    return slot_bytes;
+}
+
+// The per-sample scratch laid out for batches of S subframes: regions of S * stride entries each.  Nothing may be in flight
+// when the layout changes (the caller has flushed).
+static int ensure_frames(CtHandle h, uint32_t S, bool relayout)
 {
     const size_t need = std::max<size_t>((size_t)S * frame_stride(h), 1);
-    if (need <= h->slot_capacity) {
-        return CT_OK;
+    if (!relayout && need <= h->slot_capacity) {
+        return CT_OK;   // (a waited-for batch, the cost-measuring launch: any region that is large enough will do)
     }
-    if (2 * need > 0xffffffffull) {
-        return fail(h, CT_E_INVAL, "batch of %u subframes is too large for 32-bit result indices", S);
+    const uint64_t budget = 2 * scratch_slot_bytes() / sizeof(float4);
+    const int regions = wanted_regions(h, S, std::max<uint64_t>(budget, 2 * need));
+    size_t total = (size_t)regions * need;
+    if (total > 0xffffffffull) {
+        if (2 * need > 0xffffffffull) {
+            return fail(h, CT_E_INVAL, "batch of %u subframes is too large for 32-bit result indices", S);
+        }
+        total = (0xffffffffull / need) * need;
     }
-    if (h->d_frames_all) {
-        HIPCHK(h, hipFree(h->d_frames_all));
-        h->d_frames_all = nullptr;
-        h->slot_capacity = 0;
+    if (total > h->frames_total) {
+        if (h->d_frames_all) {
+            HIPCHK(h, hipFree(h->d_frames_all));
+            h->d_frames_all = nullptr;
+            h->frames_total = 0;
+            h->slot_capacity = 0;
+        }
+        const hipError_t e = dmalloc(&h->d_frames_all, total);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_frames_all = nullptr;
+            return fail(h, e == hipErrorOutOfMemory ? CT_E_NOMEM : CT_E_HIP, "per-sample scratch of %.1f GB: %s", (double)total * 16e-9,
+                        hipGetErrorString(e));
+        }
+        // touch it now: the first launch that writes a fresh part of a large allocation has been seen to
+        // take 30 ms longer (measured on the 3.5 GB scratch of a 256-subframe batch)
+        HIPCHK(h, hipMemsetAsync(h->d_frames_all, 0, total * sizeof(float4), h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->frames_total = total;
     }
-    HIPCHK(h, dmalloc(&h->d_frames_all, 2 * need));
-    // touch it now: the first launch that writes a fresh part of a large allocation has been seen to
-    // take 30 ms longer (measured on the 3.5 GB scratch of a 256-subframe batch)
-    HIPCHK(h, hipMemsetAsync(h->d_frames_all, 0, 2 * need * sizeof(float4), h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     h->slot_capacity = need;
+    h->n_regions = (int)std::min<size_t>((size_t)regions, h->frames_total / need);
+    h->layout_S = S;
+    h->next_slot = 0;
     return CT_OK;
 }
 
@@ -1148,7 +1218,7 @@ static int collect(CtHandle h, CtHandle_::Slot &sl)
     if (getenv("CT_TRACE")) {
         uint32_t cnt[3] = { 0, 0, 0 };
         hipMemcpy(cnt, h->d_cont_count, sizeof cnt, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[cloudtrace] estimator launch %.2f ms (suspended paths per slot now: %u %u, cursor %u)\n", ms,
+        fprintf(stderr, "[cloudtrace] estimator launch %.2f ms (suspended paths per buffer now: %u %u, cursor %u)\n", ms,
                 cnt[0], cnt[1], cnt[2]);
     }
     if (sl.accumulated) {
@@ -1156,12 +1226,6 @@ static int collect(CtHandle h, CtHandle_::Slot &sl)
         h->accum_ms += ms;
     }
     h->launches += 1;
-    if (sl.suspended) {
-        uint32_t n = 0;
-        HIPCHK(h, hipMemcpy(&n, h->d_cont_count + (&sl - h->slots), sizeof n, hipMemcpyDeviceToHost));
-        h->suspended_total += n;
-        sl.suspended = false;
-    }
     return CT_OK;
 }
 
@@ -1183,17 +1247,34 @@ static int enqueue_accumulate(CtHandle h, CtHandle_::Slot &sl, const float4 *fra
     return CT_OK;
 }
 
+// The estimator launch itself: the kernel that fits the handle and the batch.
+static int launch_estimator(CtHandle h, const BatchArgs &ba)
+{
+    if (h->exchange && !ba.cost && !ba.cont_in && !ba.cont_out && h->scene.estimator == CT_EST_DELTA) {
+        if (h->exchange == 2) {
+            HIPCHK(h, launch_render_delta_w(h->dev, ba, h->xshape, h->stream));
+        } else {
+            HIPCHK(h, launch_render_delta_x(h->dev, ba, h->xshape, h->stream));
+        }
+    } else if (h->scene.estimator == CT_EST_DELTA) {
+        HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
+    } else {
+        HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+    }
+    return CT_OK;
+}
+
 // Enqueues one launch of the estimator over S subframes.  `frames` is the dense frame buffer
-// (ct_render_subframe) or NULL for the slot's half of the scratch.  With `suspend` the launch hands its
-// surviving paths to the next one and the accumulate kernel is left to the caller's successor; the
-// paths the other slot's launch suspended are resumed in any case.  Does not wait.
+// (ct_render_subframe) or NULL for the slot's region of the scratch.  With `suspend` the launch hands its
+// surviving paths to the next one and the batch's accumulate kernel follows the launch that is max_age = n_regions - 1
+// batches younger; the paths the previous launch suspended are resumed in any case.  Does not wait.
 static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t first, uint32_t S, bool accumulate,
                         bool suspend)
 {
     CtHandle_::Slot &sl = h->slots[slot];
-    CtHandle_::Slot &other = h->slots[slot ^ 1];
     const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
     const bool dense = dense_frames != nullptr;
+    const uint32_t max_age = (uint32_t)(h->n_regions - 1);
     BatchArgs ba{};
     ba.frames = dense ? dense_frames : (simple ? slot_frames(h, slot) : h->d_frames_all);
     ba.frame_stride = (simple || dense) ? 0u : h->n_groups * 64u;
@@ -1214,17 +1295,20 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     ba.queue = sl.queue;
     ba.counters = h->d_counters;
     ba.stats = h->d_counters + kCounterCount + 1;
-    if (other.awaits_accumulate) {
-        ba.cont_in = other.cont;
-        ba.cont_in_count = h->d_cont_count + (slot ^ 1);
+    const int buf_out = (int)(h->launch_no & 1u), buf_in = buf_out ^ 1;
+    if (h->cont_live) {
+        ba.cont_in = h->cont[buf_in];
+        ba.cont_in_count = h->d_cont_count + buf_in;
         ba.cont_cursor = h->d_cont_count + 2;
         HIPCHK(h, hipMemsetAsync(h->d_cont_count + 2, 0, sizeof(uint32_t), h->stream));
     }
     if (suspend) {
-        ba.cont_out = sl.cont;
-        ba.cont_out_count = h->d_cont_count + slot;
+        ba.cont_out = h->cont[buf_out];
+        ba.cont_out_count = h->d_cont_count + buf_out;
         ba.cont_capacity = (uint32_t)h->cont_capacity;
-        HIPCHK(h, hipMemsetAsync(h->d_cont_count + slot, 0, sizeof(uint32_t), h->stream));
+        ba.max_age = std::max(1u, max_age);
+        ba.cont_total = h->d_cont_total;
+        HIPCHK(h, hipMemsetAsync(h->d_cont_count + buf_out, 0, sizeof(uint32_t), h->stream));
     }
     HIPCHK(h, hipMemsetAsync(sl.queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
     if (h->debug_invariants && !simple && !dense && h->n_groups != 0) {
@@ -1244,16 +1328,9 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         }
     } else {
         if (h->n_jobs != 0 || ba.cont_in) {
-            if (h->exchange && !ba.cost && !ba.cont_in && !ba.cont_out && h->scene.estimator == CT_EST_DELTA) {
-                if (h->exchange == 2) {
-                    HIPCHK(h, launch_render_delta_w(h->dev, ba, h->xshape, h->stream));
-                } else {
-                    HIPCHK(h, launch_render_delta_x(h->dev, ba, h->xshape, h->stream));
-                }
-            } else if (h->scene.estimator == CT_EST_DELTA) {
-                HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
-            } else {
-                HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+            const int rc = launch_estimator(h, ba);
+            if (rc != CT_OK) {
+                return rc;
             }
         }
         h->host_paths += h->own_pixels * S;
@@ -1261,22 +1338,26 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         h->iv_expected_dealt += h->hit_pixels * S;
     }
     HIPCHK(h, hipEventRecord(sl.ev_done, h->stream));
+    h->launch_no += 1;
+    h->cont_live = suspend && !simple;
     sl.first = first;
     sl.S = S;
     sl.pending = true;
     sl.accumulated = false;
     sl.awaits_accumulate = false;
-    sl.suspended = suspend;
-    // the batch whose suspended paths this launch has just finished can be accumulated now
-    if (other.awaits_accumulate) {
-        const int rc = enqueue_accumulate(h, other, slot_frames(h, slot ^ 1), false);
-        if (rc != CT_OK) {
-            return rc;
-        }
-    }
     if (accumulate) {
         if (suspend) {
             sl.awaits_accumulate = true;
+            h->waiting.push_back(slot);
+            // every batch that max_age launches have followed is complete: its accumulate kernel goes behind this launch
+            while (h->waiting.size() > (size_t)max_age) {
+                const int w = h->waiting.front();
+                h->waiting.erase(h->waiting.begin());
+                const int rc = enqueue_accumulate(h, h->slots[w], slot_frames(h, w), false);
+                if (rc != CT_OK) {
+                    return rc;
+                }
+            }
         } else {
             const int rc = enqueue_accumulate(h, sl, dense ? dense_frames : slot_frames(h, slot), dense);
             if (rc != CT_OK) {
@@ -1310,15 +1391,11 @@ static int check_invariants(CtHandle h)
     return CT_OK;
 }
 
-// Every batch in flight has finished when this returns.  A batch that is still waiting for its suspended
-// paths gets a launch that only resumes them (no jobs), then its accumulate kernel.
+// Every batch in flight has finished when this returns.  Batches that still wait for suspended paths get ONE launch that
+// only resumes them (no jobs, no suspension: everything runs to its end), then their accumulate kernels in order.
 static int flush(CtHandle h)
 {
-    for (int slot = 0; slot < 2; slot++) {
-        CtHandle_::Slot &sl = h->slots[slot];
-        if (!sl.awaits_accumulate) {
-            continue;
-        }
+    if (h->cont_live) {
         BatchArgs ba{};
         ba.frames = h->d_frames_all;
         ba.frame_stride = h->n_groups * 64u;
@@ -1328,27 +1405,25 @@ static int flush(CtHandle h)
         ba.job_group = h->d_job_group;
         ba.job_sub = h->d_job_sub;
         ba.n_jobs = 0;                  // q_begin stays all zero: every queue is empty
-        ba.first_subframe = sl.first;
-        ba.S = sl.S;
+        ba.first_subframe = 1;
+        ba.S = 0;
         ba.queue = h->d_queue;
         ba.counters = h->d_counters;
         ba.stats = h->d_counters + kCounterCount + 1;
-        ba.cont_in = sl.cont;
-        ba.cont_in_count = h->d_cont_count + slot;
+        const int buf_in = (int)((h->launch_no & 1u) ^ 1u);
+        ba.cont_in = h->cont[buf_in];
+        ba.cont_in_count = h->d_cont_count + buf_in;
         ba.cont_cursor = h->d_cont_count + 2;
         HIPCHK(h, hipMemsetAsync(h->d_cont_count + 2, 0, sizeof(uint32_t), h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
         HIPCHK(h, hipEventRecord(h->ev_flush0, h->stream));
-        if (h->scene.estimator == CT_EST_DELTA) {
-            HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
-        } else {
-            HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
-        }
-        HIPCHK(h, hipEventRecord(h->ev_flush1, h->stream));
-        const int rc = enqueue_accumulate(h, sl, slot_frames(h, slot), false);
+        const int rc = launch_estimator(h, ba);
         if (rc != CT_OK) {
             return rc;
         }
+        HIPCHK(h, hipEventRecord(h->ev_flush1, h->stream));
+        h->launch_no += 1;
+        h->cont_live = false;
         HIPCHK(h, hipEventSynchronize(h->ev_flush1));
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev_flush0, h->ev_flush1));
@@ -1357,8 +1432,15 @@ static int flush(CtHandle h)
             fprintf(stderr, "[cloudtrace] resume-only launch %.2f ms\n", ms);
         }
     }
-    for (int k = 0; k < 2; k++) {
-        const int rc = collect(h, h->slots[(h->next_slot + k) & 1]);
+    for (int w : h->waiting) {
+        const int rc = enqueue_accumulate(h, h->slots[w], slot_frames(h, w), false);
+        if (rc != CT_OK) {
+            return rc;
+        }
+    }
+    h->waiting.clear();
+    for (int k = 0; k < CtHandle_::kMaxRegions; k++) {
+        const int rc = collect(h, h->slots[k]);
         if (rc != CT_OK) {
             return rc;
         }
@@ -1477,17 +1559,10 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             return rc;
         }
     }
-    // split so that a slot of the scratch stays within its size, scratch indices fit 32 bits and the subframe offset fits
+    // split so that a region of the scratch stays within its size, scratch indices fit 32 bits and the subframe offset fits
     // the 16 bits of job_sub
     const uint64_t stride = std::max<uint64_t>(frame_stride(h), 1);
-    // (the scratch has two slots when batches are enqueued; CT_SCRATCH_GIB sets the size of one.  Default 16: the 1024-spp
-    // job of a 1024^2 frame is then ONE launch, 14 GB, instead of two of 512 -- a launch costs ~5 ms besides its samples:
-    // 3273 instead of 3226 Msamples/s -- and 28 GB of scratch are a tenth of this GPU's memory.  Allocated as needed.)
-    uint64_t slot_bytes = 16ull << 30;
-    if (const char *e = getenv("CT_SCRATCH_GIB")) {
-        slot_bytes = (uint64_t)std::min(64, std::max(1, atoi(e))) << 30;
-    }
-    uint64_t cap = std::min<uint64_t>(slot_bytes / (stride * sizeof(float4)), 0xffffffffull / (2 * stride));
+    uint64_t cap = std::min<uint64_t>(scratch_slot_bytes() / (stride * sizeof(float4)), 0xffffffffull / (2 * stride));
     cap = std::max<uint64_t>(std::min<uint64_t>(cap, 0xffffull), 1);
     uint32_t done = 0;
     // job lists are built for the size of the call's batches, not for the remainder that follows the short
@@ -1495,7 +1570,7 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
     h->jobs_hint = (uint32_t)((count + (count + cap - 1) / cap - 1) / ((count + cap - 1) / cap));
     while (done < count) {
         // what is left, cut into the fewest launches the scratch allows, all of the same size (1024 subframes at
-        // 1024^2, where the scratch holds 624: two launches of 512, not 624 + 400)
+        // 1024^2 with 8 GiB regions, which hold 624: two launches of 512, not 624 + 400)
         const uint64_t left = count - done, parts = (left + cap - 1) / cap;
         uint32_t S = (uint32_t)((left + parts - 1) / parts);
         int rc;
@@ -1504,7 +1579,11 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             // order): it is kept short, waited for, then the order is set
             rc = flush(h);
             if (rc == CT_OK) {
-                rc = ensure_frames(h, S); // sized for the batches that follow, not for this short one
+                rc = ensure_frames(h, S, true); // laid out for the batches that follow, not for this short one
+            }
+            if (rc == CT_E_NOMEM && S > 1) {
+                cap = std::max<uint64_t>(S / 2, 1);   // the device cannot give that much: more, shorter launches
+                continue;
             }
             S = std::min(S, kTuneSubframes);
             if (rc == CT_OK) {
@@ -1514,20 +1593,25 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             const bool trace = getenv("CT_TRACE") != nullptr;
             const auto t0 = std::chrono::steady_clock::now();
             rc = prepare_batches(h, S);
-            if (rc == CT_OK && (size_t)S * frame_stride(h) > h->slot_capacity) {
-                rc = flush(h); // the scratch grows: nothing may be in flight
+            const size_t need = (size_t)S * frame_stride(h);
+            if (rc == CT_OK && (need > h->slot_capacity || (!wait && S != h->layout_S))) {
+                rc = flush(h); // the layout of the scratch changes: nothing may be in flight
                 if (rc == CT_OK) {
-                    rc = ensure_frames(h, S);
+                    rc = ensure_frames(h, S, !wait);
+                }
+                if (rc == CT_E_NOMEM && S > 1) {
+                    cap = std::max<uint64_t>(S / 2, 1);
+                    continue;
                 }
             }
             const auto t1 = std::chrono::steady_clock::now();
             if (wait) {
                 rc = rc == CT_OK ? flush(h) : rc;
-                h->next_slot = 0; // synchronous batches use one slot and run every path to its end
+                h->next_slot = 0; // synchronous batches use one region and run every path to its end
             }
             const int slot = h->next_slot;
             if (rc == CT_OK) {
-                rc = collect(h, h->slots[slot]); // book the launch that used this slot two batches ago
+                rc = collect(h, h->slots[slot]); // book the launch that used this region n_regions batches ago
             }
             const auto t2 = std::chrono::steady_clock::now();
             if (rc == CT_OK) {
@@ -1537,11 +1621,11 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             if (trace) {
                 const auto t3 = std::chrono::steady_clock::now();
                 auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-                fprintf(stderr, "[cloudtrace] batch first=%u S=%u: prepare %.2f ms, slot %.2f ms, submit %.2f ms\n",
-                        first_subframe_id + done, S, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+                fprintf(stderr, "[cloudtrace] batch first=%u S=%u region %d of %d: prepare %.2f ms, slot %.2f ms, submit %.2f ms\n",
+                        first_subframe_id + done, S, slot, h->n_regions, ms(t0, t1), ms(t1, t2), ms(t2, t3));
             }
             if (!wait) {
-                h->next_slot ^= 1;
+                h->next_slot = (h->next_slot + 1) % h->n_regions;
             }
         }
         if (rc != CT_OK) {
@@ -1856,6 +1940,14 @@ extern "C" int ct_tonemap(CtHandle h, float exposure, uint8_t *rgba_host, float 
     return tonemap_impl(h, h->d_mean, exposure, rgba_host, avg_luminance_out);
 }
 
+extern "C" int ct_tonemap_async(CtHandle h, float exposure)
+{
+    NEED_NOFLUSH(h);
+    // (behind whatever is enqueued: the running mean of the batches whose accumulate kernels precede it on the stream)
+    HIPCHK(h, launch_reinhard(h->d_mean, h->scene.width, h->scene.height, exposure, h->d_colsum, h->d_avg, h->d_screen, h->stream));
+    return CT_OK;
+}
+
 extern "C" int ct_tonemap_buffer(CtHandle h, const float *mean_rgba_dev, float exposure, uint8_t *rgba_host,
                                  float *avg_luminance_out)
 {
@@ -2119,7 +2211,9 @@ extern "C" int ct_debug_suspended(CtHandle h, uint64_t *paths_out)
     if (!paths_out) {
         return fail(h, CT_E_INVAL, "paths_out is NULL");
     }
-    *paths_out = h->suspended_total;
+    unsigned long long n = 0;
+    HIPCHK(h, hipMemcpy(&n, h->d_cont_total, sizeof n, hipMemcpyDeviceToHost));
+    *paths_out = n;
     return CT_OK;
 }
 

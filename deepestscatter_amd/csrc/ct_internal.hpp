@@ -64,6 +64,9 @@ struct BatchArgs {
     uint32_t *cont_out;             // NULL: run every path to its end
     uint32_t *cont_out_count;       // zero before launch
     uint32_t cont_capacity;         // entries cont_out can hold
+    uint32_t max_age;               // a path that has been suspended this often is run to its end (>= 1 when cont_out is set):
+                                    // the host accumulates a batch once max_age further launches have run
+    unsigned long long *cont_total; // running total of suspended paths (diagnostic), or NULL
     uint32_t out_offset;            // added to a compact result index (frame_stride != 0)
     unsigned long long *counters; // kCounterCount
     unsigned long long *stats;    // kStatCount

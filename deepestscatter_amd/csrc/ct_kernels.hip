@@ -917,7 +917,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0, st_iters = 0, st_first = 0;
 
     // ---------------- resume the paths the previous launch suspended ----------------
-    bool resumed = false;   // this lane's path comes from cont_in: it is run to its end, never suspended again
+    // How often this lane's path has been suspended so far (0 = started by this launch).  A path may be handed on while its
+    // age is below ba.max_age: the host accumulates a batch only after max_age further launches, so a path that old must
+    // be run to its end here (max_age = 1: a resumed path is never suspended again, as until round 3).
+    uint32_t age = 0;
     if (ba.cont_in) {
         const uint32_t total = __builtin_amdgcn_readfirstlane(*ba.cont_in_count);
         uint32_t base = 0;
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             dfree = (w3.z >> 16) & 0xffu;
             state = (int)(w3.z >> 24);
             stepv = scale3(dir, sc.sample_step);
-            resumed = true;
+            age = w3.w;
             if (STATS) {
                 iv_resumed += 1;
             }
@@ -1020,7 +1023,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                         rad = mk3(0, 0, 0);
                         depth = 0;
                         work = 0;
-                        resumed = false;
+                        age = 0;
                         if (MODE == 1) {
                             dir = new_direction(lds.cdf, lds.guide, seed, dir);  // :86
                         }
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         // (only once this wave's own job is used up: a lane then suspends at most one path per launch, which
         // is what the next launch can resume -- 64 paths per wave -- and what cont_out is sized for)
         if (may_suspend && drained && q_next == q_end) {
-            const bool mine = state != ST_IDLE && !resumed;
+            const bool mine = state != ST_IDLE && age < ba.max_age;
             const uint64_t live = __builtin_amdgcn_ballot_w64(mine);
             if (live != 0ull) {
                 const uint32_t n = (uint32_t)__builtin_popcountll(live);
@@ -1249,6 +1252,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     if (base + n > ba.cont_capacity) {
                         atomicSub(ba.cont_out_count, n); // no room (cannot happen with the host's sizing): keep running
                         base = 0xffffffffu;
+                    } else if (ba.cont_total) {
+                        atomicAdd(ba.cont_total, (unsigned long long)n);
                     }
                 }
                 base = __builtin_amdgcn_readlane(base, __builtin_ctzll(live));
@@ -1257,7 +1262,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     e[0] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), __float_as_uint(dir.x));
                     e[1] = make_uint4(__float_as_uint(dir.y), __float_as_uint(dir.z), __float_as_uint(rad.x), __float_as_uint(rad.y));
                     e[2] = make_uint4(__float_as_uint(rad.z), seed, out_idx, __float_as_uint(xi));
-                    e[3] = make_uint4(__float_as_uint(T), __float_as_uint(inv_maxd), depth | (dfree << 16) | ((uint32_t)state << 24), 0u);
+                    e[3] = make_uint4(__float_as_uint(T), __float_as_uint(inv_maxd), depth | (dfree << 16) | ((uint32_t)state << 24), age + 1u);
                     state = ST_IDLE;
                     if (STATS) {
                         iv_suspended += 1;
@@ -1655,7 +1660,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
     uint32_t st_drained_t = 0;                                                                          // tracking visits after the wave found the job list empty
 
     // ---------------- path continuation, as in render_persistent_kernel (kContWordsDelta words per path) ----------------
-    bool resumed = false;
+    uint32_t age = 0;   // times this lane's path has been suspended (see render_persistent_kernel)
     if (ba.cont_in) {
         const uint32_t total = __builtin_amdgcn_readfirstlane(*ba.cont_in_count);
         uint32_t base = 0;
@@ -1680,7 +1685,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             dda.tdelta = mk3(__uint_as_float(w5.x), __uint_as_float(w5.y), __uint_as_float(w5.z));
             dda.by = (int32_t)w5.w;
             dda.bz = (int32_t)w6.x;
-            resumed = true;
+            age = w6.y;
             if (STATS) {
                 iv_resumed += 1;
             }
@@ -1744,7 +1749,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                         seed = tea4(__float_as_uint(p1.w), ba.first_subframe + s);
                         rad = mk3(0, 0, 0);
                         depth = 0;
-                        resumed = false;
+                        age = 0;
                         if (MODE == 1) {
                             dir = new_direction(lds.cdf, lds.guide, seed, dir);
                         }
@@ -1774,7 +1779,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                             state = ST_MARCH;
                         } else {
 #ifdef CT_DEBUG_BOUNDS
-                            if (!resumed && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to the previous batch's half)
+                            if (age == 0u && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to an earlier batch's region)
                                 printf("CT_DEBUG_BOUNDS frames[%u] outside the batch (offset %u, S %u, stride %u)\n", out_idx, ba.out_offset, ba.S, ba.frame_stride);
                                 out_idx = ba.out_offset;
                             }
@@ -1896,7 +1901,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                 }
                 if (ended) {
 #ifdef CT_DEBUG_BOUNDS
-                    if (!resumed && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to the previous batch's half)
+                    if (age == 0u && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to an earlier batch's region)
                         printf("CT_DEBUG_BOUNDS frames[%u] outside the batch (offset %u, S %u, stride %u)\n", out_idx, ba.out_offset, ba.S, ba.frame_stride);
                         out_idx = ba.out_offset;
                     }
@@ -1930,7 +1935,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         }
         if (finished) {
 #ifdef CT_DEBUG_BOUNDS
-            if (!resumed && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to the previous batch's half)
+            if (age == 0u && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to an earlier batch's region)
                 printf("CT_DEBUG_BOUNDS frames[%u] outside the batch (offset %u, S %u, stride %u)\n", out_idx, ba.out_offset, ba.S, ba.frame_stride);
                 out_idx = ba.out_offset;
             }
@@ -1947,7 +1952,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         }
         // ---------------- suspend (see render_persistent_kernel) ----------------
         if (may_suspend && drained && q_next == q_end) {
-            const bool mine = state != ST_IDLE && !resumed;
+            const bool mine = state != ST_IDLE && age < ba.max_age;
             const uint64_t live = __builtin_amdgcn_ballot_w64(mine);
             if (live != 0ull) {
                 const uint32_t n = (uint32_t)__builtin_popcountll(live);
@@ -1957,6 +1962,8 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                     if (base + n > ba.cont_capacity) {
                         atomicSub(ba.cont_out_count, n);
                         base = 0xffffffffu;
+                    } else if (ba.cont_total) {
+                        atomicAdd(ba.cont_total, (unsigned long long)n);
                     }
                 }
                 base = __builtin_amdgcn_readlane(base, __builtin_ctzll(live));
@@ -1968,7 +1975,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                     e[3] = make_uint4(__float_as_uint(dda.org.x), __float_as_uint(dda.org.y), __float_as_uint(dda.org.z), __float_as_uint(dda.t));
                     e[4] = make_uint4(__float_as_uint(dda.tmax.x), __float_as_uint(dda.tmax.y), __float_as_uint(dda.tmax.z), (uint32_t)dda.bx);
                     e[5] = make_uint4(__float_as_uint(dda.tdelta.x), __float_as_uint(dda.tdelta.y), __float_as_uint(dda.tdelta.z), (uint32_t)dda.by);
-                    e[6] = make_uint4((uint32_t)dda.bz, 0u, 0u, 0u);
+                    e[6] = make_uint4((uint32_t)dda.bz, age + 1u, 0u, 0u);
                     state = ST_IDLE;
                     if (STATS) {
                         iv_suspended += 1;

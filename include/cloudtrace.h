@@ -221,6 +221,13 @@ CT_API int ct_reset(CtHandle h);
  * (W*H*4 bytes). avg_luminance_out (optional) receives reinhard.cu:53 averageLuminance. */
 CT_API int ct_tonemap(CtHandle h, float exposure, uint8_t *rgba_host, float *avg_luminance_out);
 
+/* The same enqueued behind the batches of ct_render_accumulate_async, without waiting: the display update of
+ * Camera::render (Camera.cpp:202-210, every 10 subframes) at the reference's cadence without a host round trip per
+ * update.  It tonemaps the running mean of the batches accumulated so far -- with path continuation a batch is
+ * accumulated a few launches after it was enqueued (ct_synchronize brings everything up to date) -- into the handle's
+ * CT_BUF_SCREEN; read it with ct_download / ct_copy_to_device after ct_synchronize, or display it from the device. */
+CT_API int ct_tonemap_async(CtHandle h, float exposure);
+
 /* Camera::isConverged, Camera.cpp:232-268, evaluated on the device.  *converged_out = 1 when
  * fewer than 500 pixels are outside the 95 % interval; *unconverged_pixels_out optional. */
 CT_API int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unconverged_pixels_out);

@@ -1262,3 +1262,41 @@ def test_delta_flights_parallel_to_an_axis_or_nearly_so(mode):
         c, o = tr.counters(), orc.counters.as_dict()
         assert all(c[k] == o[k] for k in ("paths", "box_hits", "density_lookups", "inscatter_lookups", "scatter_events", "depth_capped")), (eye, c, o)
         tr.close()
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
+@pytest.mark.parametrize("max_age", ["0", "1", "5"])
+def test_short_batches_with_repeated_suspension_are_bit_exact(estimator, max_age, monkeypatch):
+    """The reference renders 10 subframes per display update (Camera.cpp:189).  Batches that short are enqueued with a ring of
+    scratch regions: a path may be handed from launch to launch several times (BatchArgs::max_age) and a batch is
+    accumulated once max_age further launches have run.  Whatever the ring's length (CT_MAX_AGE: 0 = chosen from the batch's
+    duration, 1 = round 2's two regions, 5 = six regions) the frame equals the waited-for one bit for bit, every sample is
+    written exactly once (invariants armed: NaN-filled scratch, dealt + resumed == written + suspended), and the display
+    update enqueued behind the batches (ct_tonemap_async) shows what ct_tonemap shows."""
+    tex = ds.make_procedural_cloud(96)
+    w = h = 160
+    ref = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+    ref.render_accumulate(1, 100)
+    want = (ref.mean(), ref.m2(), ref.counters(), ref.tonemap(0.4)[0])
+    ref.close()
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    monkeypatch.setenv("CT_MAX_AGE", max_age)
+    tr = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+    first = 1
+    for n in [10] * 4 + [3] * 10 + [10] * 3:        # (a change of batch size re-lays the ring out: a flush in between)
+        tr.render_accumulate_async(first, n)
+        tr.tonemap_async(0.4)
+        first += n
+    tr.synchronize()
+    tr.tonemap_async(0.4)
+    tr.synchronize()
+    screen = tr.download(_lib.CT_BUF_SCREEN)
+    got = (tr.mean(), tr.m2(), tr.counters())
+    iv = tr.debug_invariants()
+    suspended = tr.debug_suspended()
+    tr.close()
+    assert iv["armed"] == 1 and iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+    assert iv["resumed"] == iv["suspended"] == suspended > 0, (iv, suspended)
+    assert got[2] == want[2]
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(np.asarray(screen).reshape(h, w, 4), want[3])

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Progressive rendering at the reference's cadence: Camera::render does 10 subframes, tonemaps, and returns to the display
+loop (Camera.cpp:189-214).  Measures ms per update and Msamples/s for enqueued batches of --spp subframes with the display
+update (ct_tonemap_async) behind each, against the same job as one long batch.
+
+    python tools/progressive_bench.py [--spp 10] [--updates 100] [--estimator 0] [--volume 512] [--size 1024]
+"""
+import argparse, json, os, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+
+
+def run(a, spp, updates, tonemap=True):
+    import deepestscatter_amd as ds
+    tex = run.tex
+    tr = ds.CloudTracer(tex, width=a.size, height=a.size, estimator=a.estimator)
+    tr.render_accumulate(1, 32)                       # cost-measuring launch of the pose
+    first = 33
+    for _ in range(max(4, 64 // spp)):                # warm-up: scratch ring, job list for this batch size
+        tr.render_accumulate_async(first, spp); first += spp
+    tr.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        tr.render_accumulate_async(first, spp); first += spp
+        if tonemap:
+            tr.tonemap_async(0.4)
+    tr.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"spp_per_update": spp, "updates": updates, "tonemap_every_update": tonemap, "ms_per_update": dt / updates * 1e3,
+           "Msamples_per_s": a.size * a.size * spp * updates / dt / 1e6, "suspended_paths": tr.debug_suspended(),
+           "checksum": float(tr.mean().astype(np.float64).sum())}
+    tr.close()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--spp", type=int, nargs="+", default=[10])
+    ap.add_argument("--updates", type=int, default=100)
+    ap.add_argument("--estimator", type=int, default=0)
+    ap.add_argument("--volume", type=int, default=512)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--reference-spp", type=int, default=1000, help="the long batch the rate is compared with (0 = skip)")
+    a = ap.parse_args()
+    import deepestscatter_amd as ds
+    run.tex = ds.make_procedural_cloud(a.volume)
+    res = {"max_age_env": os.environ.get("CT_MAX_AGE", ""), "runs": []}
+    for spp in a.spp:
+        r = run(a, spp, max(2, a.updates * 10 // spp) if spp != 10 else a.updates)
+        print(json.dumps(r), flush=True)
+        res["runs"].append(r)
+    if a.reference_spp:
+        r = run(a, a.reference_spp, 2, tonemap=False)
+        print("reference", json.dumps(r), flush=True)
+        for x in res["runs"]:
+            x["fraction_of_long_batch_rate"] = x["Msamples_per_s"] / r["Msamples_per_s"]
+        res["reference"] = r
+    print("progressive_summary", json.dumps(res))

@@ -60,6 +60,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-delta-leg", action="store_true", help="skip the DELTA-estimator run reported beside the headline")
+    ap.add_argument("--no-progressive-leg", action="store_true", help="skip the 10-subframes-per-update run (the reference's display cadence)")
+    ap.add_argument("--merge", default="reduce", choices=("reduce", "gather"),
+                    help="N > 1: how the shards' [mean | M2] reach rank 0 -- one SUM reduce of the full frame (default) or a gather of "
+                         "every rank's own tiles, 1/N of the bytes (SURVEY section 8e)")
     ap.add_argument("--simple-kernel", action="store_true", help="A/B: one thread per pixel, nested loops")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a box with one GPU)")
@@ -69,35 +73,84 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(tex, ins, width, height, mode, target_s):
-    """The oracle (our CPU port of the reference; the reference has no CPU path) on all host
-    cores, on a bounded sample of the SAME workload: the centred 256x256 window."""
+def subjob_camera(width, height, win=256):
+    """The centred win x win window of the width x height frame as a frame of its own: pixel (i, j) of the small frame
+    looks along the ray of pixel (x0 + i, y0 + j) of the big one when U and V shrink by win / width and win / height
+    (cameraCommon.cuh:22: d = pixel / size * 2 - 1; the window is centred, so the offset term vanishes).  Same part of
+    the cloud, same footprint per pixel -- the sub-job both the CPU leg and the GPU's "same sub-job" leg render."""
+    import deepestscatter_amd as ds
+    w, h = min(win, width), min(win, height)
+    eye = (2.5, -0.4, 0.0)
+    U, V, Wv = ds.calculate_camera_variables(eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 30.0, width / height)
+    return w, h, eye, np.asarray(U, np.float32) * np.float32(w / width), np.asarray(V, np.float32) * np.float32(h / height), np.asarray(Wv, np.float32)
+
+
+def cpu_baseline(ds, tex, ins, width, height, mode, target_s):
+    """The oracle (our CPU port of the reference; the reference has no CPU path) on all host cores, on a bounded sample of
+    the SAME workload: the centred 256x256 window (subjob_camera), and the GPU timed on that identical sub-job beside it
+     -- whose frame must equal the oracle's bit for bit, so the ratio compares two computations of
+    the same numbers."""
     sys.path.insert(0, str(ROOT / "tests"))
     import _oracle as O
     cores = int(O.lib(True).orc_max_threads())
-    orc = O.Oracle(tex, width, height, mode=mode, fast=True, inscatter=ins, threads=cores)
-    x0, y0 = width // 2 - 128, height // 2 - 128
-    win = (max(x0, 0), max(y0, 0), min(x0 + 256, width), min(y0 + 256, height))
-    npix = (win[2] - win[0]) * (win[3] - win[1])
+    w, h, eye, U, V, Wv = subjob_camera(width, height)
+    orc = O.Oracle(tex, w, h, mode=mode, fast=True, inscatter=ins, threads=cores)
+    orc.set_camera(eye, U, V, Wv)
     t0 = time.perf_counter()
-    orc.render_subframe(1, win)
+    orc.render_subframe(1)
     t1 = time.perf_counter() - t0
     spp = int(min(max(round(target_s / max(t1, 1e-3)), 1), 64))
-    before = orc.counters.as_dict()
+    orc2 = O.Oracle(tex, w, h, mode=mode, fast=True, inscatter=ins, threads=cores)
+    orc2.set_camera(eye, U, V, Wv)
     t0 = time.perf_counter()
-    for sid in range(2, 2 + spp):
-        orc.render_subframe(sid, win)
+    ref_mean, _ = orc2.render(spp)
     dt = time.perf_counter() - t0
-    after = orc.counters.as_dict()
-    lookups = (after["density_lookups"] + after["inscatter_lookups"]) - (before["density_lookups"] + before["inscatter_lookups"])
-    return {
-        "value": npix * spp / dt / 1e6,
+    c = orc2.counters.as_dict()
+    lookups = c["density_lookups"] + c["inscatter_lookups"]
+    out = {
+        "value": w * h * spp / dt / 1e6,
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"centred {win[2]-win[0]}x{win[3]-win[1]} window x {spp} spp of the same volume/camera ({dt:.1f} s)",
+        "sample": f"centred {w}x{h} window of the {width}x{height} frame as a frame of its own x {spp} spp, same volume ({dt:.1f} s)",
         "lookups_per_s": lookups / dt,
     }
+    # the GPU on that identical sub-job: same camera, same subframes; two passes (the first measures the job costs)
+    try:
+        t = ds.CloudTracer(tex, width=w, height=h, mode=mode)
+        t.set_camera(eye, U, V, Wv)
+        t.render_accumulate(1, spp)
+        same = bool(np.array_equal(t.mean(), ref_mean))
+        t.reset()
+        t0 = time.perf_counter()
+        t.render_accumulate(1, spp)
+        gdt = time.perf_counter() - t0
+        t.close()
+        out["gpu_same_subjob"] = {"value": w * h * spp / gdt / 1e6, "unit": "Msamples/s", "ms": gdt * 1e3,
+                                  "bit_identical_to_the_cpu_result": same,
+                                  "note": "one waited-for launch of a 65k-pixel frame: launch-bound, far below the headline rate"}
+        out["gpu_over_cpu_same_subjob"] = out["gpu_same_subjob"]["value"] / out["value"]
+    except Exception as e:  # the ratio is optional; the bench line is not
+        out["gpu_same_subjob"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def progressive_leg(tr, W, H, first, spp=10, updates=100):
+    """The reference's cadence (Camera::render, Camera.cpp:189-214): `spp` subframes, then the display update.  Enqueued
+    batches with ct_tonemap_async behind each; paths and unstarted jobs pass from launch to launch."""
+    for _ in range(8):                                  # the ring of scratch regions and the job list for this batch size
+        tr.render_accumulate_async(first, spp)
+        first += spp
+    tr.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        tr.render_accumulate_async(first, spp)
+        tr.tonemap_async(0.4)
+        first += spp
+    tr.synchronize()
+    dt = time.perf_counter() - t0
+    return {"spp_per_update": spp, "updates": updates, "tonemap_every_update": True, "ms_per_update": dt / updates * 1e3,
+            "value": W * H * spp * updates / dt / 1e6, "unit": "Msamples/s"}, first
 
 
 def pmc_traffic(args, S):
@@ -115,7 +168,7 @@ def pmc_traffic(args, S):
     if not Path(exe).exists() or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("CT_BENCH_CHILD"):
         return None
     # (one step of the child is S subframes: one launch when its per-sample scratch fits a slot, else several equal ones)
-    child = [sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-delta-leg",
+    child = [sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-delta-leg", "--no-progressive-leg",
              "--no-pmc-traffic", "--volume", str(args.volume), "--width", str(args.width), "--height", str(args.height),
              "--spp-per-step", str(S), "--mode", str(args.mode), "--estimator", str(args.estimator)]
     env = dict(os.environ, CT_BENCH_CHILD="1", TMPDIR="/tmp")
@@ -285,7 +338,8 @@ def main():
     tex = ds.make_procedural_cloud(args.volume)
     flags = _lib.CT_FLAG_SIMPLE_KERNEL if args.simple_kernel else 0
     from deepestscatter_amd.distributed import ShardedTracer
-    st = ShardedTracer(tex, ds.SceneParams(width=W, height=H, mode=args.mode, estimator=args.estimator, flags=flags), rank, world, local_rank)
+    st = ShardedTracer(tex, ds.SceneParams(width=W, height=H, mode=args.mode, estimator=args.estimator, flags=flags), rank, world, local_rank,
+                       merge=args.merge)
     tr = st.tracer
     setup_s = time.perf_counter() - t_setup
 
@@ -335,9 +389,30 @@ def main():
     k1, f1 = tr.counters(), tr.fetch_counters()
     r1, a1, l1 = tr.kernel_time()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    own_elapsed = elapsed
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    multi = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # what the driver can check: every rank took part in the collectives on a device of its own
+        per_rank = [torch.zeros(4, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        merge_ms = st.merge_ms()
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, float(torch.cuda.current_device()), merge_ms, float(tr.kernel_time()[0] - r0) / max(args.steps, 1)],
+                            dtype=torch.float64, device=coll_dev)
+        dist.all_gather(per_rank, mine)
+        ones = torch.ones(1, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(ones)
+        rows = [[float(v) for v in p.tolist()] for p in per_rank]
+        multi = {
+            "rccl_ranks": int(ones.item()),                     # ranks that contributed to an all-reduce of ones
+            "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+            "devices": [int(r[1]) for r in rows],               # the device each rank rendered and reduced on
+            "ms_per_step_per_rank": [r[0] for r in rows],
+            "estimator_ms_per_step_per_rank": [r[3] for r in rows],
+            "merge": args.merge,
+            "merge_ms_per_step_per_rank": [r[2] for r in rows], # copies into the staging buffer + the collective, device time
+        }
     elapsed = float(t.item())
 
     total_samples = W * H * S * args.steps
@@ -393,14 +468,43 @@ def main():
             here = {}
     achieved_bytes = max(issued_bytes / launches, traffic or 0.0)
     achieved = achieved_bytes * launches / sec / 1e9 if sec > 0 else 0.0
+    # Three named fractions (round-2 review): what the kernel asked for, what the memory system moved for it, and the ratio.
+    useful_GBps = issued_bytes / sec / 1e9 if sec > 0 else 0.0
+    traffic_GBps = traffic * launches / sec / 1e9 if (traffic and sec > 0) else None
+    # A latency view beside the bandwidth one.  Every marching lane has ONE footprint in flight (the next position needs the
+    # fetched density), so Little's law bounds the line-fill rate by lanes-in-flight / miss latency; the other ceiling is the
+    # rate at which the fabric fills random 128-B lines at all (the probe).  The kernel's own rate is its L2 misses per second.
+    miss_per_launch = pmc_extra.get("tcc_miss_per_full_launch")
+    lines_per_s = miss_per_launch * launches / sec if (miss_per_launch and sec > 0) else None
+    probe_lines_per_s = (here.get("random_128B_line_GBps_this_run") or MEASURED_RANDOM_LINE_GBS) * 1e9 / 128.0
+    resident_lanes = tr.launch_lanes() if hasattr(tr, "launch_lanes") else 256 * 24 * 64
+    lane_occ = 0.41   # SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), profiles/r02r
+    hbm_miss_ns, mall_hit_ns = 900 / 2.4, 545 / 2.4     # MI355X_MICROARCH.md, idle chip, one lane
+    latency_model = {
+        "lines_per_s": lines_per_s, "probe_random_lines_per_s": probe_lines_per_s,
+        "frac_of_line_fill_rate": lines_per_s / probe_lines_per_s if lines_per_s else None,
+        "resident_lanes": resident_lanes, "lane_occupancy": lane_occ,
+        "miss_latency_ns_idle_chip": {"infinity_cache_hit": mall_hit_ns, "hbm": hbm_miss_ns},
+        "littles_law_ceiling_lines_per_s": resident_lanes * lane_occ / (hbm_miss_ns * 1e-9),
+        "frac_of_littles_law_ceiling": lines_per_s / (resident_lanes * lane_occ / (hbm_miss_ns * 1e-9)) if lines_per_s else None,
+        "reading": "the kernel fills lines at frac_of_line_fill_rate of what the fabric delivers to a pure random-line gather and at "
+                   "frac_of_littles_law_ceiling of what its resident lanes could keep in flight if they did nothing but wait for "
+                   "misses: it is near the fabric's line-fill rate, not near its own concurrency limit -- and in between fetches its "
+                   "lanes compute at 41 % occupancy, which is why removing misses buys little (DESIGN.md 4.3)",
+    }
     roofline = {
         "bound": "hbm",
         "kernel": "render_simple_kernel" if args.simple_kernel else ("render_delta_kernel" if args.estimator else "render_persistent_kernel"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "achieved_is": "max(issued bytes, PMC traffic) per launch / average launch duration" if traffic else
+        "achieved_is": "max(issued bytes, PMC traffic) per launch / average launch duration; the traffic is bytes across the L2's memory side, "
+                       "so Infinity-Cache hits are inside it: an upper bound on HBM bytes.  frac = traffic_frac; useful_frac is what the kernel asked for" if traffic else
                        "issued bytes only: no PMC traffic was measured in this run (N > 1, --no-pmc-traffic or no profiler); the "
                        "traffic-based fraction is on the N = 1 line",
         "traffic": traffic, "traffic_source": traffic_source,
+        "useful_frac": useful_GBps / HBM_PEAK_GBS,        # 8 B per footprint the kernel loaded + 16 B per sample written
+        "traffic_frac": traffic_GBps / HBM_PEAK_GBS if traffic_GBps else None,   # bytes across the L2's memory side (Infinity-Cache hits included)
+        "waste_ratio": traffic * launches / issued_bytes if (traffic and issued_bytes) else None,   # a 128-B line per 16 requested / 8 useful bytes
+        "latency_model": latency_model,
         "issued_bytes_per_launch": issued_bytes / launches,
         "issued_GBps": issued_bytes / sec / 1e9 if sec > 0 else 0.0,
         "algorithmic_bytes_per_launch": alg_bytes / launches,
@@ -450,11 +554,18 @@ def main():
         "setup_s": setup_s,
     }
 
+    if multi:
+        out["multi_gpu"] = multi
+        out["rccl_ranks"] = multi["rccl_ranks"]
+    if rank == 0 and world == 1 and not args.simple_kernel and not args.no_progressive_leg and not args.sync_steps:
+        prog, nxt = progressive_leg(tr, W, H, nxt)
+        prog["fraction_of_headline"] = prog["value"] / value
+        out["progressive_10spp"] = prog
     if rank == 0 and world == 1 and args.estimator == 0 and not args.simple_kernel and not args.no_delta_leg:
         out["delta_estimator"] = delta_leg(ds, tex, W, H, args.mode, S, max(args.steps, 1))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ins = tr.inscatter()
-        out["cpu_baseline"] = cpu_baseline(tex, ins, W, H, args.mode, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(ds, tex, ins, W, H, args.mode, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
     tr.close()

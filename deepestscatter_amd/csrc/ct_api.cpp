@@ -75,12 +75,15 @@ struct CtHandle_ {
     size_t frames_total = 0;               // float4 allocated
     size_t slot_capacity = 0;              // float4 per region
     uint32_t layout_S = 0;                 // batch size the regions were laid out for
-    uint32_t *d_cont_count = nullptr;      // [2] entries in cont[i], [2] = resume cursor
+    uint32_t *left[2] = { nullptr, nullptr }; // job remainders handed on the same way (BatchArgs::left_out)
+    size_t left_capacity = 0;              // entries per buffer: one per wave
+    uint32_t *d_cont_count = nullptr;      // [0,1] entries in cont[i], [2] resume cursor, [3,4] entries in left[i], [5] its cursor
     unsigned long long *d_cont_total = nullptr; // paths handed from one launch to the next so far (ct_debug_suspended)
     size_t cont_capacity = 0;              // entries per buffer
     hipEvent_t ev_flush0 = nullptr, ev_flush1 = nullptr;
     bool continuation = true;              // CT_CONTINUATION=0: async batches run every path to its end
     int max_age_override = 0;              // CT_MAX_AGE=n: n + 1 regions whatever the batch size (0 = by batch duration)
+    bool hand_on_jobs = true;              // CT_HAND_ON_JOBS=0: a wave finishes its own job before it suspends (A/B)
     // work queue of the persistent kernel (rebuilt when the camera moves)
     float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
     float4 *d_advance = nullptr;      // per pixel: pre-walked prefix of the primary march (MARCH estimator)
@@ -89,6 +92,7 @@ struct CtHandle_ {
     uint32_t *d_job_group = nullptr, *d_job_sub = nullptr; // job list of the current batch size
     uint32_t n_groups = 0, groups_capacity = 0;
     uint32_t n_jobs = 0, jobs_capacity = 0, jobs_S = 0;
+    bool jobs_brief = false;          // the list was laid out for short launches (short_batch)
     uint32_t jobs_hint = 0;           // batch size the caller asked for last (job lists are built for it)
     // subframes per job at most (cheap groups), and the bounces (x cost unit) a job's lane is expected to run.
     // Re-swept on the final kernels (8 / 256 before): +4.3 % at 512^3, +5.6 % at 1024^3, +2.6 % at 256^3, +1.3 % DELTA
@@ -279,7 +283,7 @@ static void release(CtHandle h)
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
         if (p) {
@@ -740,8 +744,8 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, dmalloc(&h->d_colsum, s->width));
     HIPCHK(h, dmalloc(&h->d_avg, 2)); // average luminance + the fused tonemap kernel's grid barrier
     HIPCHK(h, dmalloc(&h->d_queue, kQueueWords));
-    HIPCHK(h, dmalloc(&h->d_cont_count, 3));
-    HIPCHK(h, hipMemsetAsync(h->d_cont_count, 0, 3 * sizeof(uint32_t), h->stream));
+    HIPCHK(h, dmalloc(&h->d_cont_count, 6));
+    HIPCHK(h, hipMemsetAsync(h->d_cont_count, 0, 6 * sizeof(uint32_t), h->stream));
     // a lane suspends at most one path per launch, and a launch resumes up to 64 paths per wave: the same number
     h->cont_capacity = (size_t)h->shape.blocks * h->shape.threads;
     HIPCHK(h, hipEventCreate(&h->ev_flush0));
@@ -752,6 +756,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     if (h->exchange) {
         h->continuation = false;   // (the exchange kernels run every path to its end)
     }
+    if (const char *e = getenv("CT_HAND_ON_JOBS")) {
+        h->hand_on_jobs = atoi(e) != 0;
+    }
     if (const char *e = getenv("CT_MAX_AGE")) {
         h->max_age_override = std::min(CtHandle_::kMaxRegions - 1, std::max(0, atoi(e)));
     }
@@ -759,6 +766,10 @@ static int create_impl(const CtScene *s, CtHandle h)
     HIPCHK(h, hipMemsetAsync(h->d_cont_total, 0, sizeof(unsigned long long), h->stream));
     for (auto &c : h->cont) {
         HIPCHK(h, dmalloc(&c, h->cont_capacity * (s->estimator == CT_EST_DELTA ? kContWordsDelta : kContWords)));
+    }
+    h->left_capacity = h->cont_capacity / 64;   // a wave hands on at most the one job it is working on
+    for (auto &c : h->left) {
+        HIPCHK(h, dmalloc(&c, h->left_capacity * kLeftWords));
     }
     for (auto &sl : h->slots) {
         HIPCHK(h, dmalloc(&sl.queue, kQueueWords));
@@ -812,7 +823,7 @@ extern "C" int ct_create(const CtScene *s, CtHandle *out)
     if (!s->mie_host || !s->chopped_mie_host || s->mie_count != (uint32_t)kMieN) {
         return fail(nullptr, CT_E_INVAL, "Mie tables must be %d floats each", kMieN);
     }
-    if (s->width == 0 || s->height == 0 || s->width > 16384 || s->height > 4096) {
+    if (s->width == 0 || s->height == 0 || s->width > 12288 || s->height > 4096) {   // (width: the tonemap kernel keeps a row of column sums in LDS)
         return fail(nullptr, CT_E_INVAL, "frame %ux%u out of range (seed packing x*4096+y needs H <= 4096)", s->width,
                     s->height);
     }
@@ -962,12 +973,22 @@ static int rebuild_queue(CtHandle h)
     return CT_OK;
 }
 
+// A launch of about 5 ms or less (10-40 subframes of a 1024^2 frame: the reference's display cadence, Camera.cpp:189).  Such a
+// launch works on EVERY pixel group at once instead of a few neighbouring ones for a thousand subframes each, and its paths
+// miss L2 half again as often at the same instruction count (profiles/r03f/pmc_prog.txt: hit rate 41 % instead of 62 %); what
+// helps is keeping an XCD on a compact part of the image -- per-XCD queues over 16 regions -- with single-subframe jobs for
+// every group deeper than four bounces and refills of 16 lanes at a time: 5.43 -> 4.74 ms per 10-subframe update.
+static bool short_batch(CtHandle h, uint32_t S)
+{
+    return (double)S * (double)std::max<uint64_t>(h->hit_pixels, 1) < 4.0e7;
+}
+
 // Job list for batches of S subframes.  A job is (group, subframe range); its length is chosen
 // so that a job's expected serial work per lane stays bounded: groups whose paths are deep get
 // one-subframe jobs, cheap groups up to 16 subframes per job (Handle::job_max, job_work).
 static int build_jobs(CtHandle h, uint32_t S)
 {
-    if (h->jobs_S >= S) {
+    if (h->jobs_S >= S && h->jobs_brief == short_batch(h, S)) {
         return CT_OK; // a list for a larger batch serves a smaller one (the kernel clips the jobs)
     }
     S = std::max(S, h->jobs_hint);
@@ -976,7 +997,11 @@ static int build_jobs(CtHandle h, uint32_t S)
     // equal shares of the measured cost (path depth + the primary march), not of the pixel count.
     // cost units per bounce (BatchArgs::cost): MARCH counts fetches + 4 per bounce, DELTA bounces
     const float unit = (h->scene.estimator == CT_EST_DELTA) ? 1.f : 16.f;
-    const uint32_t nq = (h->queues_enabled && h->n_groups >= (uint32_t)kQueues) ? (uint32_t)kQueues : 1u;
+    const bool brief = short_batch(h, S);
+    const bool queues = (h->queues_enabled || (brief && !getenv("CT_XCD_QUEUES"))) && !(h->scene.flags & CT_FLAG_SIMPLE_KERNEL);
+    const uint32_t nq = (queues && h->n_groups >= (uint32_t)kQueues) ? (uint32_t)kQueues : 1u;
+    const uint32_t regions_wanted = (brief && !h->queues_enabled && !getenv("CT_XCD_REGIONS")) ? 16u : h->regions;
+    const float job_work = (brief && !getenv("CT_JOB_WORK")) ? 4.f : h->job_work;
     // Groups whose paths are deep (mean cost >= shared_depth bounces) go to the shared queue.
     const float shared_cost = h->shared_depth * unit;
     std::vector<uint8_t> queue_of(h->n_groups, 0);
@@ -998,7 +1023,7 @@ static int build_jobs(CtHandle h, uint32_t S)
             // h->regions compact image regions of equal cost, dealt round-robin to the queues: every
             // XCD still works on 1/8 of the image (a handful of compact pieces), and errors of the
             // cost estimate, which are correlated in space, average out over its pieces
-            const uint32_t regions = std::max(nq, h->regions);
+            const uint32_t regions = std::max(nq, regions_wanted);
             const uint32_t r = (uint32_t)std::min<double>(regions - 1, std::floor((run + 0.5 * w) / total * regions));
             queue_of[g] = (uint8_t)(r % nq);
             run += w;
@@ -1018,7 +1043,7 @@ static int build_jobs(CtHandle h, uint32_t S)
             q_weight[x] += (double)d + unit;
             uint32_t len = h->job_max;
             if (d > 0.f) {
-                len = (uint32_t)std::min((float)h->job_max, std::max(1.f, h->job_work * unit / d));
+                len = (uint32_t)std::min((float)h->job_max, std::max(1.f, job_work * unit / d));
             }
             for (uint32_t s0 = 0; s0 < S; s0 += len) {
                 jg.push_back(g);
@@ -1056,6 +1081,7 @@ static int build_jobs(CtHandle h, uint32_t S)
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     h->jobs_S = S;
+    h->jobs_brief = brief;
     return CT_OK;
 }
 
@@ -1250,16 +1276,20 @@ static int enqueue_accumulate(CtHandle h, CtHandle_::Slot &sl, const float4 *fra
 // The estimator launch itself: the kernel that fits the handle and the batch.
 static int launch_estimator(CtHandle h, const BatchArgs &ba)
 {
+    DevScene sc = h->dev;
+    if (ba.S != 0 && short_batch(h, ba.S) && !getenv("CT_REGEN_MIN")) {
+        sc.regen_min = 16;   // (see short_batch)
+    }
     if (h->exchange && !ba.cost && !ba.cont_in && !ba.cont_out && h->scene.estimator == CT_EST_DELTA) {
         if (h->exchange == 2) {
-            HIPCHK(h, launch_render_delta_w(h->dev, ba, h->xshape, h->stream));
+            HIPCHK(h, launch_render_delta_w(sc, ba, h->xshape, h->stream));
         } else {
-            HIPCHK(h, launch_render_delta_x(h->dev, ba, h->xshape, h->stream));
+            HIPCHK(h, launch_render_delta_x(sc, ba, h->xshape, h->stream));
         }
     } else if (h->scene.estimator == CT_EST_DELTA) {
-        HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
+        HIPCHK(h, launch_render_delta(sc, ba, h->shape, h->stream));
     } else {
-        HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+        HIPCHK(h, launch_render_persistent(sc, ba, h->shape, h->stream));
     }
     return CT_OK;
 }
@@ -1300,7 +1330,11 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         ba.cont_in = h->cont[buf_in];
         ba.cont_in_count = h->d_cont_count + buf_in;
         ba.cont_cursor = h->d_cont_count + 2;
+        ba.left_in = h->left[buf_in];
+        ba.left_in_count = h->d_cont_count + 3 + buf_in;
+        ba.left_cursor = h->d_cont_count + 5;
         HIPCHK(h, hipMemsetAsync(h->d_cont_count + 2, 0, sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_cont_count + 5, 0, sizeof(uint32_t), h->stream));
     }
     if (suspend) {
         ba.cont_out = h->cont[buf_out];
@@ -1308,7 +1342,13 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         ba.cont_capacity = (uint32_t)h->cont_capacity;
         ba.max_age = std::max(1u, max_age);
         ba.cont_total = h->d_cont_total;
+        if (h->hand_on_jobs) {
+            ba.left_out = h->left[buf_out];
+            ba.left_out_count = h->d_cont_count + 3 + buf_out;
+            ba.left_capacity = (uint32_t)h->left_capacity;
+        }
         HIPCHK(h, hipMemsetAsync(h->d_cont_count + buf_out, 0, sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_cont_count + 3 + buf_out, 0, sizeof(uint32_t), h->stream));
     }
     HIPCHK(h, hipMemsetAsync(sl.queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
     if (h->debug_invariants && !simple && !dense && h->n_groups != 0) {
@@ -1414,7 +1454,11 @@ static int flush(CtHandle h)
         ba.cont_in = h->cont[buf_in];
         ba.cont_in_count = h->d_cont_count + buf_in;
         ba.cont_cursor = h->d_cont_count + 2;
+        ba.left_in = h->left[buf_in];
+        ba.left_in_count = h->d_cont_count + 3 + buf_in;
+        ba.left_cursor = h->d_cont_count + 5;
         HIPCHK(h, hipMemsetAsync(h->d_cont_count + 2, 0, sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_cont_count + 5, 0, sizeof(uint32_t), h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
         HIPCHK(h, hipEventRecord(h->ev_flush0, h->stream));
         const int rc = launch_estimator(h, ba);
@@ -1455,7 +1499,7 @@ static int prepare_batches(CtHandle h, uint32_t S)
     if (simple) {
         return CT_OK;
     }
-    if (h->queue_dirty || h->jobs_S < S) {
+    if (h->queue_dirty || h->jobs_S < S || h->jobs_brief != short_batch(h, S)) {
         int rc = flush(h);
         if (rc == CT_OK && h->queue_dirty) {
             rc = rebuild_queue(h);

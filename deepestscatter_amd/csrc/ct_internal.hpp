@@ -16,6 +16,7 @@ constexpr int kStatCount = 72;      // scheduler diagnostics (ct_debug_stats): [
                                     // (samples dealt, paths resumed, results written, paths suspended; STATS kernels only)
 constexpr int kContWords = 16;      // words of a suspended path (render_persistent_kernel)
 constexpr int kContWordsDelta = 32; // the same for render_delta_kernel (its DDA state rides along)
+constexpr int kLeftWords = 8;        // words of a job handed to the next launch (BatchArgs::left_out)
 constexpr int kQueueFlag = 32;       // word of the queue array (its own 128-B line) that says "job list empty"
 constexpr int kQueueWords = 64;      // size of a queue array
 constexpr int kQueues = 8;          // one job queue per XCD (MI355X: 8 XCDs, each with its own L2)
@@ -67,6 +68,17 @@ struct BatchArgs {
     uint32_t max_age;               // a path that has been suspended this often is run to its end (>= 1 when cont_out is set):
                                     // the host accumulates a batch once max_age further launches have run
     unsigned long long *cont_total; // running total of suspended paths (diagnostic), or NULL
+    // Jobs handed on like paths: a wave that learns that the job list is empty while it still has samples of its own job
+    // to start (its lanes are busy with long paths) does not hold the launch up until lanes come free -- it writes the
+    // rest of the job to left_out (kLeftWords words: group, first subframe of the job, next and end sample, the batch's
+    // scratch offset and first subframe id, the age its samples start with) and the next launch's waves take those
+    // before the job list.  Same samples, same seeds, same result indices: only the launch that runs them changes.
+    const uint32_t *left_in;        // NULL: none
+    const uint32_t *left_in_count;
+    uint32_t *left_cursor;          // zero before launch
+    uint32_t *left_out;             // NULL: every wave finishes its job
+    uint32_t *left_out_count;       // zero before launch
+    uint32_t left_capacity;
     uint32_t out_offset;            // added to a compact result index (frame_stride != 0)
     unsigned long long *counters; // kCounterCount
     unsigned long long *stats;    // kStatCount

@@ -782,6 +782,55 @@ CT_DEV uint32_t xcd_id()
     return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (uint32_t)(kQueues - 1);
 }
 
+// A job the previous launch handed on (BatchArgs::left_in).  Wave-uniform.
+struct JobState {
+    uint32_t g, s0, next, end;   // pixel group, first subframe (relative to `first`), samples [next, end) still to start
+    uint32_t off, first, age;    // the batch's scratch offset and first subframe id; the age its samples start with
+};
+
+CT_DEV bool take_leftover(const BatchArgs &ba, uint32_t lane, bool &left_done, JobState &job)
+{
+    if (!ba.left_in || left_done) {
+        return false;
+    }
+    uint32_t i = 0;
+    if (lane == 0) {
+        i = atomicAdd(ba.left_cursor, 1u);
+    }
+    i = __builtin_amdgcn_readfirstlane(i);
+    if (i >= __builtin_amdgcn_readfirstlane(*ba.left_in_count)) {
+        left_done = true;
+        return false;
+    }
+    const uint32_t *r = ba.left_in + (size_t)i * kLeftWords;
+    job.g = __builtin_amdgcn_readfirstlane(r[0]);
+    job.s0 = __builtin_amdgcn_readfirstlane(r[1]);
+    job.next = __builtin_amdgcn_readfirstlane(r[2]);
+    job.end = __builtin_amdgcn_readfirstlane(r[3]);
+    job.off = __builtin_amdgcn_readfirstlane(r[4]);
+    job.first = __builtin_amdgcn_readfirstlane(r[5]);
+    job.age = __builtin_amdgcn_readfirstlane(r[6]);
+    return true;
+}
+
+// The rest of this wave's job goes to the next launch (see BatchArgs::left_out).  Returns false if there is no room.
+CT_DEV bool hand_on_job(const BatchArgs &ba, uint32_t lane, const JobState &job)
+{
+    uint32_t i = 0;
+    if (lane == 0) {
+        i = atomicAdd(ba.left_out_count, 1u);
+        if (i >= ba.left_capacity) {
+            atomicSub(ba.left_out_count, 1u);
+            i = 0xffffffffu;
+        } else {
+            uint4 *r = (uint4 *)(ba.left_out + (size_t)i * kLeftWords);
+            r[0] = make_uint4(job.g, job.s0, job.next, job.end);
+            r[1] = make_uint4(job.off, job.first, job.age + 1u, 0u);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(i) != 0xffffffffu;
+}
+
 // Next job for this wave: from the queue it is working on (first the shared one), else from its
 // XCD's, else from the following ones.  Wave-uniform.  Returns false when every queue is empty.
 CT_DEV bool take_job(const BatchArgs &ba, uint32_t lane, uint32_t &q_cur, uint32_t &q_tried, uint32_t &job)
@@ -900,7 +949,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     int state = ST_IDLE;
 
     // wave-uniform bookkeeping (lives in SGPRs): the current job and the samples left in it
-    uint32_t q_next = 0, q_end = 0, job_g = 0, job_s0 = 0;
+    JobState job{ 0, 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
+    bool left_done = false;
     uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
     uint32_t c_dl = 0, c_il = 0, c_cap = 0; // per-lane tallies
@@ -963,8 +1013,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             // that takes the last job raises a flag in a cache line of its own: reading the job counter
             // itself, the target of every wave's atomics, cost 10-30 % of the launch
             const uint32_t empty = __builtin_amdgcn_readfirstlane(__atomic_load_n(ba.queue + kQueueFlag, __ATOMIC_RELAXED));
-            if (empty != 0u && q_next == q_end) {
-                drained = true;
+            if (empty != 0u) {
+                // (samples of its own job that this wave has not started go to the next launch with its paths)
+                if (job.next != job.end && ba.left_out && job.age < ba.max_age && hand_on_job(ba, lane, job)) {
+                    job.next = job.end;
+                }
+                if (job.next == job.end) {
+                    drained = true;
+                }
             }
         }
         if (STATS) {
@@ -976,8 +1032,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         // ---------------- regenerate ----------------
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if ((n_idle >= sc.regen_min || n_idle == 64u) && !(drained && q_next == q_end)) {
-            if (q_next == q_end) {
+        if ((n_idle >= sc.regen_min || n_idle == 64u) && !(drained && job.next == job.end)) {
+            if (job.next == job.end && !take_leftover(ba, lane, left_done, job)) {
                 uint32_t j = 0;
                 if (!take_job(ba, lane, q_cur, q_tried, j)) {
                     drained = true;
@@ -985,28 +1041,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     if (STATS) {
                         st_stolen += (q_tried != 0u) ? 1u : 0u;
                     }
-
                     const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
-                    job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
-                    job_s0 = sub & 0xffffu;
-                    q_next = 0;
+                    job.g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
+                    job.s0 = sub & 0xffffu;
+                    job.next = 0;
                     // the list may have been built for a larger batch: clip the job to this launch's subframes
-                    q_end = (job_s0 < ba.S ? min(sub >> 16, ba.S - job_s0) : 0u) * 64u;
+                    job.end = (job.s0 < ba.S ? min(sub >> 16, ba.S - job.s0) : 0u) * 64u;
+                    job.off = ba.out_offset;
+                    job.first = ba.first_subframe;
+                    job.age = 0;
                 }
             }
-            if (q_next != q_end) {
-                const uint32_t avail = q_end - q_next;
+            if (job.next != job.end) {
+                const uint32_t avail = job.end - job.next;
                 if (STATS) {
                     st_regen += 1;
                     st_regen_l += min(n_idle, avail);
                 }
                 const uint32_t rank = lane_rank(idle);
                 const bool take = (state == ST_IDLE) && rank < avail;
-                const uint32_t q = q_next + rank;
-                q_next += min(n_idle, avail);
+                const uint32_t q = job.next + rank;
+                job.next += min(n_idle, avail);
                 if (take) {
-                    const uint32_t s = job_s0 + (q >> 6), l = q & 63u;
-                    const uint32_t g = job_g;
+                    const uint32_t s = job.s0 + (q >> 6), l = q & 63u;
+                    const uint32_t g = job.g;
                     const uint32_t pixel = ba.pixels[g * 64u + l];
                     if (pixel != 0xffffffffu) {
                         if (STATS) {
@@ -1014,16 +1072,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                         }
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                        out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + (g * 64u + l) : pixel;
+                        out_idx = ba.frame_stride ? job.off + s * ba.frame_stride + (g * 64u + l) : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f; // image jobs list hitting pixels only; point tasks may miss
                         dir = mk3(p1.x, p1.y, p1.z);
-                        seed = tea4(__float_as_uint(p1.w), ba.first_subframe + s); // :21
+                        seed = tea4(__float_as_uint(p1.w), job.first + s); // :21
                         rad = mk3(0, 0, 0);
                         depth = 0;
                         work = 0;
-                        age = 0;
+                        age = job.age;
                         if (MODE == 1) {
                             dir = new_direction(lds.cdf, lds.guide, seed, dir);  // :86
                         }
@@ -1066,7 +1124,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         const uint64_t bouncing = __builtin_amdgcn_ballot_w64(state == ST_BOUNCE);
         const uint32_t nm = (uint32_t)__builtin_popcountll(marching);
         const uint32_t nb = (uint32_t)__builtin_popcountll(bouncing);
-        if ((marching | bouncing) == 0 && drained && q_next == q_end) {
+        if ((marching | bouncing) == 0 && drained && job.next == job.end) {
             break;
         }
         // (everything idle but samples left: both phases below are no-ops and the loop regenerates)
@@ -1241,7 +1299,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         // ---------------- suspend: nothing left to take, hand the surviving paths to the next launch ----------------
         // (only once this wave's own job is used up: a lane then suspends at most one path per launch, which
         // is what the next launch can resume -- 64 paths per wave -- and what cont_out is sized for)
-        if (may_suspend && drained && q_next == q_end) {
+        if (may_suspend && drained && job.next == job.end) {
             const bool mine = state != ST_IDLE && age < ba.max_age;
             const uint64_t live = __builtin_amdgcn_ballot_w64(mine);
             if (live != 0ull) {
@@ -1313,8 +1371,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             atomicAdd(&ba.stats[14], (unsigned long long)st_stolen);
             atomicMax(&ba.stats[15], (unsigned long long)st_iters);
             const unsigned long long t_end = wall_clock64();
+#ifdef CT_STATS_FINE   // (analysis builds: 0.25 ms / 0.05 ms bins for launches of a few milliseconds)
+            atomicAdd(&ba.stats[16 + min((unsigned long long)23, (t_end - t_start) / 25000ull)], 1ull);
+            atomicAdd(&ba.stats[40 + min((unsigned long long)23, (t_end - (t_drained ? t_drained : t_end)) / 5000ull)], 1ull);
+#else
             atomicAdd(&ba.stats[16 + min((unsigned long long)23, (t_end - t_start) / 500000ull)], 1ull);
             atomicAdd(&ba.stats[40 + min((unsigned long long)23, (t_end - (t_drained ? t_drained : t_end)) / 50000ull)], 1ull);
+#endif
             atomicAdd(&ba.stats[64], (unsigned long long)sv[7]);
             atomicAdd(&ba.stats[65], (unsigned long long)sv[8]);
             atomicAdd(&ba.stats[66], (unsigned long long)sv[9]);
@@ -1649,7 +1712,8 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
     uint32_t seed = 0, depth = 0, out_idx = 0, group = 0;
     int state = ST_IDLE;
 
-    uint32_t q_next = 0, q_end = 0, job_g = 0, job_s0 = 0;
+    JobState job{ 0, 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
+    bool left_done = false;
     uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
     uint32_t c_dl = 0, c_il = 0, c_cap = 0;
@@ -1700,40 +1764,49 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         visit += 1;
         if (may_suspend && single_queue && !drained && sc.hint_period != 0u && (visit & (sc.hint_period - 1u)) == 0u) {
             const uint32_t empty = __builtin_amdgcn_readfirstlane(__atomic_load_n(ba.queue + kQueueFlag, __ATOMIC_RELAXED));
-            if (empty != 0u && q_next == q_end) {
-                drained = true;
+            if (empty != 0u) {
+                // (samples of its own job that this wave has not started go to the next launch with its paths)
+                if (job.next != job.end && ba.left_out && job.age < ba.max_age && hand_on_job(ba, lane, job)) {
+                    job.next = job.end;
+                }
+                if (job.next == job.end) {
+                    drained = true;
+                }
             }
         }
         // ---------------- regenerate ----------------
         const uint64_t idle = __builtin_amdgcn_ballot_w64(state == ST_IDLE);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if ((n_idle >= sc.regen_min || n_idle == 64u) && !(drained && q_next == q_end)) {
-            if (q_next == q_end) {
+        if ((n_idle >= sc.regen_min || n_idle == 64u) && !(drained && job.next == job.end)) {
+            if (job.next == job.end && !take_leftover(ba, lane, left_done, job)) {
                 uint32_t j = 0;
                 if (!take_job(ba, lane, q_cur, q_tried, j)) {
                     drained = true;
                 } else {
                     const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
-                    job_g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
-                    job_s0 = sub & 0xffffu;
-                    q_next = 0;
+                    job.g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
+                    job.s0 = sub & 0xffffu;
+                    job.next = 0;
                     // the list may have been built for a larger batch: clip the job to this launch's subframes
-                    q_end = (job_s0 < ba.S ? min(sub >> 16, ba.S - job_s0) : 0u) * 64u;
+                    job.end = (job.s0 < ba.S ? min(sub >> 16, ba.S - job.s0) : 0u) * 64u;
+                    job.off = ba.out_offset;
+                    job.first = ba.first_subframe;
+                    job.age = 0;
                 }
             }
-            if (q_next != q_end) {
-                const uint32_t avail = q_end - q_next;
+            if (job.next != job.end) {
+                const uint32_t avail = job.end - job.next;
                 if (STATS) {
                     st_regen += 1;
                     st_regen_l += min(n_idle, avail);
                 }
                 const uint32_t rank = lane_rank(idle);
                 const bool take = (state == ST_IDLE) && rank < avail;
-                const uint32_t q = q_next + rank;
-                q_next += min(n_idle, avail);
+                const uint32_t q = job.next + rank;
+                job.next += min(n_idle, avail);
                 if (take) {
-                    const uint32_t s = job_s0 + (q >> 6), l = q & 63u;
-                    const uint32_t g = job_g;
+                    const uint32_t s = job.s0 + (q >> 6), l = q & 63u;
+                    const uint32_t g = job.g;
                     const uint32_t pixel = ba.pixels[g * 64u + l];
                     if (pixel != 0xffffffffu) {
                         if (STATS) {
@@ -1741,15 +1814,15 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                         }
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                        out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + (g * 64u + l) : pixel;
+                        out_idx = ba.frame_stride ? job.off + s * ba.frame_stride + (g * 64u + l) : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f;
                         dir = mk3(p1.x, p1.y, p1.z);
-                        seed = tea4(__float_as_uint(p1.w), ba.first_subframe + s);
+                        seed = tea4(__float_as_uint(p1.w), job.first + s);
                         rad = mk3(0, 0, 0);
                         depth = 0;
-                        age = 0;
+                        age = job.age;
                         if (MODE == 1) {
                             dir = new_direction(lds.cdf, lds.guide, seed, dir);
                         }
@@ -1798,7 +1871,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         const uint64_t bouncing = __builtin_amdgcn_ballot_w64(state == ST_BOUNCE);
         const uint32_t nm = (uint32_t)__builtin_popcountll(marching);
         const uint32_t nb = (uint32_t)__builtin_popcountll(bouncing);
-        if ((marching | bouncing) == 0 && drained && q_next == q_end) {
+        if ((marching | bouncing) == 0 && drained && job.next == job.end) {
             break;
         }
         // (everything idle but samples left: both phases below are no-ops and the loop regenerates)
@@ -1951,7 +2024,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             state = ST_IDLE;
         }
         // ---------------- suspend (see render_persistent_kernel) ----------------
-        if (may_suspend && drained && q_next == q_end) {
+        if (may_suspend && drained && job.next == job.end) {
             const bool mine = state != ST_IDLE && age < ba.max_age;
             const uint64_t live = __builtin_amdgcn_ballot_w64(mine);
             if (live != 0ull) {
@@ -2476,12 +2549,50 @@ __global__ __launch_bounds__(256) void reinhard_fused_kernel(const float4 *__res
     __shared__ float avg_s;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
     const float DELTA = 0.00001f;
-    for (uint32_t x = gtid; x < width; x += gsize) { // firstPass, reinhard.cu:29-40
-        float sum = 0;
-        for (uint32_t y = 0; y < height; y++) {
-            sum += luminance4(mean[(size_t)y * width + x]) + DELTA;
+    // firstPass, reinhard.cu:29-40: per column, sum += luminance + DELTA for y = 0 .. height-1 -- IN THAT ORDER (float adds do
+    // not commute with regrouping, and the tonemapped bytes must equal the reference's arithmetic).  A thread per column that
+    // loads as it adds is a chain of `height` dependent memory round trips (1.9 ms at 1024^2: more than a 10-subframe
+    // update's accumulate and half of its estimator launch).  So the loads are taken out of the chain: a block takes 32
+    // columns, its 256 threads fetch 64 rows of them at once and leave luminance + DELTA in LDS, and 32 threads add the 64
+    // values of their column in order; only the adds are serial.
+    {
+        __shared__ float tile[64][33];
+        const uint32_t groups = (width + 31u) / 32u;
+        const uint32_t cx = threadIdx.x & 31u, ry = threadIdx.x >> 5;   // 32 columns x 8 rows per pass
+        for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+            const uint32_t x = g * 32u + cx;
+            float sum = 0;
+            for (uint32_t y0 = 0; y0 < height; y0 += 64u) {
+                float v[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) {
+                    const uint32_t y = y0 + ry + 8u * k;
+                    v[k] = (x < width && y < height) ? luminance4(mean[(size_t)y * width + x]) + DELTA : 0.f;
+                }
+                __syncthreads();   // (the previous tile has been added up)
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) {
+                    tile[ry + 8u * k][cx] = v[k];
+                }
+                __syncthreads();
+                if (threadIdx.x < 32u && x < width) {
+                    const uint32_t rows = min(64u, height - y0);
+                    if (rows == 64u) {
+#pragma unroll
+                        for (uint32_t r = 0; r < 64u; r++) {
+                            sum += tile[r][cx];
+                        }
+                    } else {
+                        for (uint32_t r = 0; r < rows; r++) {
+                            sum += tile[r][cx];
+                        }
+                    }
+                }
+            }
+            if (threadIdx.x < 32u && x < width) {
+                __hip_atomic_store(column_sums + x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        __hip_atomic_store(column_sums + x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2536,6 +2647,9 @@ hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, 
     }
     const uint32_t pixels = width * height;
     const uint32_t blocks = std::min<uint32_t>((uint32_t)cus, (pixels + 255u) / 256u);
+    if ((size_t)width * sizeof(float) > 48u * 1024u) {
+        return hipErrorInvalidValue;   // (the column sums of a row do not fit the kernel's LDS: frames up to 12288 pixels wide)
+    }
     hipError_t e = hipMemsetAsync(avg + 1, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) {
         return e;

@@ -21,6 +21,38 @@ def env_rank_world() -> tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def shard_indices(width: int, height: int, world: int) -> list[np.ndarray]:
+    """Flat pixel indices (y * width + x) of every shard's tiles, in ascending order: the tile-contiguous layout of the
+    gather merge ("an all-gather over a tile-contiguous layout moves 1/G of the bytes")."""
+    from .cloudtrace import shard_mask
+    return [np.flatnonzero(shard_mask(width, height, r, world).reshape(-1)).astype(np.int64) for r in range(world)]
+
+
+def frame_gather(local, indices: list, packed, recv: list | None, dst: int = 0):
+    """The same merge with 1/world of the bytes: every rank packs the pixels of its own tiles (`indices[rank]`, flat pixel
+    indices) from `local` [2, H, W, 4] into `packed` [2, n_max, 4], the packs are gathered on rank `dst`, which writes each
+    into its place.  `recv`: world tensors like `packed` on rank dst, None elsewhere.  Exact: no arithmetic at all."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return local
+    rank = dist.get_rank()
+    flat = local.view(2, -1, 4)
+    n = indices[rank].numel()
+    packed[:, :n] = flat.index_select(1, indices[rank])
+    staged = local.is_cuda and dist.get_backend() != "nccl"    # rehearsal backends: through the host
+    src = packed.cpu() if staged else packed
+    lst = None
+    if rank == dst:
+        lst = [r.cpu() for r in recv] if staged else recv
+    dist.gather(src, lst, dst=dst)
+    if rank == dst:
+        for r, got in enumerate(lst):
+            if r != dst:
+                k = indices[r].numel()
+                flat.index_copy_(1, indices[r], got[:, :k].to(local.device))
+    return local
+
+
 def frame_reduce(local, dst: int = 0):
     """SUM-reduce a per-rank radiance buffer (torch tensor, any device) to rank `dst`.  Tiles are
     disjoint and foreign pixels are exactly 0, so the sum is the merged frame."""
@@ -50,10 +82,12 @@ class ShardedTracer:
     with or without waiting in between."""
 
     def __init__(self, density: np.ndarray, params: SceneParams, rank: int, world: int, local_rank: int = 0,
-                 stage_always: bool = False):
+                 stage_always: bool = False, merge: str = "reduce"):
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
+        self.merge = merge if world > 1 else "reduce"   # "gather": every rank sends only its own tiles (1/world of the bytes)
+        self._merge_events, self._merge_host_ms, self._merges = [], 0.0, 0
         params.shard_index, params.shard_count, params.device = rank, world, local_rank
         self.tracer = CloudTracer(density, params)
         self.stage = world > 1 or stage_always       # stage_always: single-rank rehearsal of the staged path
@@ -62,6 +96,12 @@ class ShardedTracer:
         self._lagging = False
         self._merged_subframes = 0
         self.stream = None
+        if self.merge == "gather":
+            idx = shard_indices(params.width, params.height, world)
+            n_max = max(len(i) for i in idx)
+            self._idx = [torch.from_numpy(i).cuda() for i in idx]
+            self._packed = torch.zeros((2, n_max, 4), dtype=torch.float32, device="cuda")
+            self._recv = [torch.zeros_like(self._packed) for _ in range(world)] if rank == 0 else None
         if self.stage:
             torch.cuda.synchronize()                 # `merged` is zeroed before another stream touches it
             self.stream = torch.cuda.Stream()
@@ -75,22 +115,48 @@ class ShardedTracer:
     def merged_m2(self):
         return self.merged[1]
 
+    def _collective(self):
+        if self.merge == "gather":
+            frame_gather(self.merged, self._idx, self._packed, self._recv, 0)
+        else:
+            frame_reduce(self.merged, 0)
+
     def _reduce(self):
         import torch.distributed as dist
         on_stream = not (dist.is_available() and dist.is_initialized()) or dist.get_backend() == "nccl"
         if on_stream:
             with self.torch.cuda.stream(self.stream):
-                frame_reduce(self.merged, 0)
+                self._collective()
         else:
             # rehearsal backends stage through the host: wait for the copy first
             self.stream.synchronize()
-            frame_reduce(self.merged, 0)
+            self._collective()
 
     def _stage(self, wait: bool):
+        import time
+        e0 = self.torch.cuda.Event(enable_timing=True)
+        e1 = self.torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(self.stream)
         copy = self.tracer.copy_to_device if wait else self.tracer.copy_to_device_async
         copy(_lib.CT_BUF_MEAN, self.merged[0].data_ptr(), self._nbytes)
         copy(_lib.CT_BUF_M2, self.merged[1].data_ptr(), self._nbytes)
         self._reduce()
+        e1.record(self.stream)
+        self._merge_events.append((e0, e1))
+        self._merge_host_ms += (time.perf_counter() - t0) * 1e3
+        self._merges += 1
+
+    def merge_ms(self) -> float:
+        """Device time per merge (the two copies into the staging buffer + the collective), averaged over the merges so far;
+        with a rehearsal backend, whose collective runs on the host, the host time of the call instead."""
+        if not self._merges:
+            return 0.0
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+            return self._merge_host_ms / self._merges
+        self.stream.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._merge_events) / len(self._merge_events)
 
     def step(self, first_subframe: int, count: int):
         """Render + accumulate `count` subframes of this shard, then reduce [mean | M2] to rank 0.

@@ -385,6 +385,12 @@ class CloudTracer:
         # running after they had found the job queue empty (0.5 ms bins)
         d["wave_end_hist_5ms"] = [int(v) for v in out[16:40]]
         d["wave_end_minus_drained_hist_0p5ms"] = [int(v) for v in out[40:64]]
+        ex = np.zeros(72, np.uint64)
+        check(self.L.ct_debug_stats_ex(self.h, _p(ex), 72), self.h)
+        # of the march fetches: the lane's previous fetch was in the same 128-B brick line / a lower lane of the wave
+        # fetches the same line in the same instruction (what a brick cache in LDS could find: DESIGN.md 4.3)
+        d["march_fetch_same_line_as_lanes_previous"] = int(ex[68])
+        d["march_fetch_line_shared_with_a_lower_lane"] = int(ex[69])
         d["raw"] = [int(v) for v in out]
         d["watchdog"] = int(out[63])     # exchange kernels: waves that gave up on a bounded wait (must be 0)
         return d

@@ -2231,6 +2231,21 @@ extern "C" int ct_debug_stats(CtHandle h, uint64_t out[64])
     return CT_OK;
 }
 
+extern "C" int ct_debug_stats_ex(CtHandle h, uint64_t *out, uint32_t count)
+{
+    NEED(h);
+    if (!out || count > (uint32_t)kStatCount) {
+        return fail(h, CT_E_INVAL, "out is NULL or count > %d", kStatCount);
+    }
+    unsigned long long c[kStatCount];
+    HIPCHK(h, hipMemcpyAsync(c, h->d_counters + kCounterCount + 1, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (uint32_t i = 0; i < count; i++) {
+        out[i] = c[i];
+    }
+    return CT_OK;
+}
+
 extern "C" int ct_debug_memory(CtHandle h, uint64_t out[8])
 {
     NEED(h);

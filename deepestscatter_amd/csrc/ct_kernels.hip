@@ -965,6 +965,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     // scheduler diagnostics (STATS builds only), see ct_debug_stats
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0, st_iters = 0, st_first = 0;
+    uint32_t st_same_line = 0, st_dup_line = 0, st_prev_line = 0xffffffffu;   // brick-line reuse of the march fetches (STATS)
 
     // ---------------- resume the paths the previous launch suspended ----------------
     // How often this lane's path has been suspended so far (0 = started by this launch).  A path may be handed on while its
@@ -1231,6 +1232,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 work += 1u;
                 if (STATS) {
                     st_fetch += 1;
+                    // (round-3 question: would a brick cache in LDS find anything?  The 128-B line of this footprint against
+                    // the lane's previous one, and against the lines the wave's other lanes fetch in this same instruction.)
+                    {
+                        const float fx = fmaf(pos.x, sc.sx, -0.5f), fy = fmaf(pos.y, sc.sy, -0.5f), fz = fmaf(pos.z, sc.sz, -0.5f);
+                        const uint32_t lx = (uint32_t)(floor_to_int(fx) + sc.m_bias_x), ly = (uint32_t)(floor_to_int(fy) + sc.brick_bias),
+                                       lz = (uint32_t)(floor_to_int(fz) + sc.brick_bias);
+                        const uint32_t line = __umul24(lz >> 2, (uint32_t)sc.m_gxy) + __umul24(ly >> 2, (uint32_t)sc.m_gx) + (__umul24(lx, 43691u) >> 17);
+                        st_same_line += (line == st_prev_line) ? 1u : 0u;
+                        st_prev_line = line;
+                        const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+                        bool dup = false;
+                        for (uint32_t i = 0; i < 64u; i++) {
+                            const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)line, (int)i);
+                            dup = dup || (((act >> i) & 1ull) != 0ull && i < lane && other == line);
+                        }
+                        st_dup_line += dup ? 1u : 0u;
+                    }
                     st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
                     st_zero_d0 += ((cell.x | cell.y) == 0u && dfree == 0u) ? 1u : 0u;
                     st_zero_d1 += ((cell.x | cell.y) == 0u && dfree == 1u) ? 1u : 0u;
@@ -1342,10 +1360,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         vals[i] = v;
     }
     if (STATS) {
-        uint32_t sv[11] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1, st_skip_iters, st_first,
-                            iv_dealt, iv_resumed, iv_written, iv_suspended };
+        uint32_t sv[13] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1, st_skip_iters, st_first,
+                            iv_dealt, iv_resumed, iv_written, iv_suspended, st_same_line, st_dup_line };
 #pragma unroll
-        for (int i = 0; i < 11; i++) {
+        for (int i = 0; i < 13; i++) {
             uint32_t v = sv[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -1382,6 +1400,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             atomicAdd(&ba.stats[65], (unsigned long long)sv[8]);
             atomicAdd(&ba.stats[66], (unsigned long long)sv[9]);
             atomicAdd(&ba.stats[67], (unsigned long long)sv[10]);
+            atomicAdd(&ba.stats[68], (unsigned long long)sv[11]);
+            atomicAdd(&ba.stats[69], (unsigned long long)sv[12]);
         }
     }
     if (lane == 0) {

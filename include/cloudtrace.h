@@ -330,6 +330,8 @@ CT_API int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_
  * scatter phases, scatter lanes, fetched march steps, fetched steps whose 8 texels were all 0,
  * skipped (replayed) march steps, skip-loop trips (wave level), rest reserved. */
 CT_API int ct_debug_stats(CtHandle h, uint64_t out[64]);
+/* All `count` <= 72 diagnostic words (64..67: path conservation, 68..69: brick-line reuse of the march fetches). */
+CT_API int ct_debug_stats_ex(CtHandle h, uint64_t *out, uint32_t count);
 /* Paths that ct_render_accumulate_async launches have handed to their successors so far (diagnostic). */
 CT_API int ct_debug_suspended(CtHandle h, uint64_t *paths_out);
 

@@ -55,7 +55,7 @@ struct CtHandle_ {
     // short batches (the reference renders 10 subframes per display update, Camera.cpp:189) get more regions, so that a
     // launch never has to wait for a path that an earlier one handed to it.
     // A slot owns a region, its queue counters and its events; the suspended paths alternate between two buffers.
-    static constexpr int kMaxRegions = 16;
+    static constexpr int kMaxRegions = 64;
     struct Slot {
         uint32_t *queue = nullptr;
         hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_done = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr;
@@ -980,7 +980,8 @@ static int rebuild_queue(CtHandle h)
 // every group deeper than four bounces and refills of 16 lanes at a time: 5.43 -> 4.74 ms per 10-subframe update.
 static bool short_batch(CtHandle h, uint32_t S)
 {
-    return (double)S * (double)std::max<uint64_t>(h->hit_pixels, 1) < 4.0e7;
+    // (MARCH only: the DELTA kernel, which makes a sixteenth of the fetches, loses 3 % with this layout -- 3.94 vs 3.82 ms)
+    return h->scene.estimator != CT_EST_DELTA && (double)S * (double)std::max<uint64_t>(h->hit_pixels, 1) < 4.0e7;
 }
 
 // Job list for batches of S subframes.  A job is (group, subframe range); its length is chosen
@@ -1190,10 +1191,11 @@ static int ensure_frames(CtHandle h, uint32_t S, bool relayout)
         return CT_OK;   // (a waited-for batch, the cost-measuring launch: any region that is large enough will do)
     }
     const uint64_t budget = 2 * scratch_slot_bytes() / sizeof(float4);
-    const int regions = wanted_regions(h, S, std::max<uint64_t>(budget, 2 * need));
+    // (a waited-for batch needs one region; the others are allocated when batches are first enqueued)
+    const int regions = relayout ? wanted_regions(h, S, std::max<uint64_t>(budget, 2 * need)) : 1;
     size_t total = (size_t)regions * need;
     if (total > 0xffffffffull) {
-        if (2 * need > 0xffffffffull) {
+        if ((relayout ? 2 : 1) * need > 0xffffffffull) {
             return fail(h, CT_E_INVAL, "batch of %u subframes is too large for 32-bit result indices", S);
         }
         total = (0xffffffffull / need) * need;
@@ -1623,7 +1625,7 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             // order): it is kept short, waited for, then the order is set
             rc = flush(h);
             if (rc == CT_OK) {
-                rc = ensure_frames(h, S, true); // laid out for the batches that follow, not for this short one
+                rc = ensure_frames(h, S, !wait); // laid out for the batches that follow, not for this short one
             }
             if (rc == CT_E_NOMEM && S > 1) {
                 cap = std::max<uint64_t>(S / 2, 1);   // the device cannot give that much: more, shorter launches
@@ -1638,7 +1640,7 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             const auto t0 = std::chrono::steady_clock::now();
             rc = prepare_batches(h, S);
             const size_t need = (size_t)S * frame_stride(h);
-            if (rc == CT_OK && (need > h->slot_capacity || (!wait && S != h->layout_S))) {
+            if (rc == CT_OK && (need > h->slot_capacity || (!wait && (S != h->layout_S || h->n_regions < 2)))) {
                 rc = flush(h); // the layout of the scratch changes: nothing may be in flight
                 if (rc == CT_OK) {
                     rc = ensure_frames(h, S, !wait);

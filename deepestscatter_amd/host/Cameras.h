@@ -170,8 +170,9 @@ namespace DeepestScatter
             const bool look = !headless || subframeId % 40 == 0;
             if (!(look && isConverged()) && !(maxSubframes && subframeId >= maxSubframes))
             {
-                // headless: one batch up to the next point where anything is read (a batch of 40 costs 20 ms where
-                // four of 10 cost 37: T(S) = 5.7 ms + 0.362 ms x S at 1024^2); results do not depend on the batching
+                // headless: one batch up to the next point where anything is read (at 1024^2 a batch of 40 costs 15.4 ms where
+                // four of 10 cost 18.5: a short launch has every pixel group in flight at once and misses L2 half again as
+                // often); results do not depend on the batching
                 uint32_t count = headless ? 40 - subframeId % 40 : subframesPerUpdate;
                 if (maxSubframes) count = std::min(count, maxSubframes - subframeId);
                 auto* pt = dynamic_cast<PathTracingRenderer*>(renderer.get());

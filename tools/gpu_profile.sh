@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_${1:-r01}
 rm -rf "$OUT"; mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-delta-leg --no-pmc-traffic ${BENCH_EXTRA:-}"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-delta-leg --no-progressive-leg --no-pmc-traffic ${BENCH_EXTRA:-}"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 i=0
 for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \

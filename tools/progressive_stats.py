@@ -7,8 +7,11 @@ sys.path.insert(0, str(ROOT))
 os.environ["CT_STATS"] = "1"
 import deepestscatter_amd as ds
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-tex = ds.make_procedural_cloud(512)
-tr = ds.CloudTracer(tex, width=1024, height=1024)
+vol = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+size = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+shards = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+tex = ds.make_procedural_cloud(vol)
+tr = ds.CloudTracer(tex, width=size, height=size, shard_index=0, shard_count=shards)
 tr.render_accumulate(1, 32)
 first = 33
 for _ in range(8):

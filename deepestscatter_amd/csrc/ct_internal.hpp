@@ -102,9 +102,12 @@ inline void split_queues_evenly(BatchArgs &ba)
 }
 
 // Tile -> shard map (also exported as ct_tile_owner).
+#ifndef CT_SHARD_SHIFT
+#define CT_SHARD_SHIFT 0   // experiment: interleave blocks of 2^k x 2^k tiles instead of single tiles
+#endif
 __host__ __device__ inline uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_t shard_count)
 {
-    return shard_count <= 1 ? 0u : (tx + 3u * ty) % shard_count;
+    return shard_count <= 1 ? 0u : ((tx >> CT_SHARD_SHIFT) + 3u * (ty >> CT_SHARD_SHIFT)) % shard_count;
 }
 
 hipError_t launch_build_bricks(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,

@@ -36,6 +36,17 @@
 
 #include "../include/ct_fmath.h"
 
+/* -DORC_LIBM: the same restatement with the C library's expf / logf / sincosf / powf in place of ct_fmath.h's polynomials
+ * (libct_oracle_libm.so).  The kernels and the bit-exact oracle share ct_fmath.h, so an error in it would pass every
+ * parity test; this build shares nothing of it and must agree with them statistically (a path whose xi > T or isInBox flips
+ * on the last ulp goes elsewhere, so not bit for bit): tests/test_oracle_basics.py::test_oracle_with_libm_math_agrees. */
+#ifdef ORC_LIBM
+#define ct_expf(x) expf(x)
+#define ct_logf(x) logf(x)
+#define ct_powf(x, y) powf((x), (y))
+#define ct_sincosf(x, s, c) sincosf((x), (s), (c))
+#endif
+
 #ifdef _OPENMP
 #include <omp.h>
 #endif

@@ -90,15 +90,17 @@ def build(force: bool = False) -> None:
 _LIB = None
 
 
-def lib(fast: bool = False):
-    """Load the oracle. fast=True picks the -mavx2 -mfma build when this CPU supports it."""
+def lib(fast=False):
+    """Load the oracle. fast=True picks the -mavx2 -mfma build when this CPU supports it; fast="libm" the build on libm's math."""
     global _LIB
     key = "fma" if (fast and _cpu_has("fma") and _cpu_has("avx2")) else "base"
+    if fast == "libm":
+        key = "libm"      # the restatement on the C library's math (statistical agreement only; ORC_LIBM in ct_oracle.c)
     if _LIB is None:
         _LIB = {}
     if key in _LIB:
         return _LIB[key]
-    name = "libct_oracle_fma.so" if key == "fma" else "libct_oracle.so"
+    name = {"fma": "libct_oracle_fma.so", "libm": "libct_oracle_libm.so"}.get(key, "libct_oracle.so")
     path = ORACLE_DIR / name
     build(force=not path.exists())   # also rebuilds a library older than its source before it is loaded
     L = C.CDLL(str(path))

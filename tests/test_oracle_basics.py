@@ -479,3 +479,33 @@ def test_independent_woodcock_tracker_agrees_with_the_delta_twin():
     se = np.sqrt((va.mean() + vb.mean()) / (spp * 256))
     assert b.mean() > 0.05 and abs(a.mean() - b.mean()) <= 1.96 * se
     assert glob.counters.density_lookups > 5 * grid.counters.density_lookups
+
+
+def test_oracle_with_libm_math_agrees():
+    """The kernels and the bit-exact oracle share include/ct_fmath.h, so an error in its polynomials would pass every parity
+    test.  libct_oracle_libm.so is the same restatement on the C library's expf / logf / sincosf / powf: most paths are
+    still identical (the two differ by an ulp here and there, which moves a path only when a comparison flips), the image
+    agrees closely, and nothing is biased."""
+    import deepestscatter_amd as ds
+    tex = ds.make_procedural_cloud(48)
+    w = h = 40
+    spp = 96
+    a = O.Oracle(tex, w, h, fast=False)
+    b = O.Oracle(tex, w, h, fast="libm", inscatter=a.inscatter)
+    assert b.L is not a.L
+    am, a2 = a.render(spp)
+    bm, b2 = b.render(spp)
+    x, y = am[..., 0].astype(np.float64), bm[..., 0].astype(np.float64)
+    lit = x > 0
+    assert lit.sum() > 200
+    # an ulp in a sine moves every later position by an ulp, so few pixels are bit-identical -- but the image differs by
+    # 1e-4 in relative L2, inside the north star's 1e-3 even across math libraries (no path-changing branch flip matters)
+    assert np.linalg.norm(x - y) / np.linalg.norm(x) < 1e-3
+    va, vb = a2[..., 0].astype(np.float64) / (spp - 1), b2[..., 0].astype(np.float64) / (spp - 1)
+    se = np.sqrt((va[lit].mean() + vb[lit].mean()) / (spp * lit.sum()))
+    assert abs(x[lit].mean() - y[lit].mean()) < 1.96 * se        # (far inside: the samples are mostly the same ones)
+    # the shadow volume, a pure function of the texture: identical up to the last unit of a byte here and there
+    full = np.empty_like(a.inscatter)
+    b.L.orc_inscatter(C.byref(b.scene), full.ctypes.data_as(C.c_void_p), 0)
+    d = np.abs(full.astype(np.int32) - a.inscatter.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 0.01

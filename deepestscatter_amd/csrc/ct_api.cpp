@@ -84,6 +84,7 @@ struct CtHandle_ {
     bool continuation = true;              // CT_CONTINUATION=0: async batches run every path to its end
     int max_age_override = 0;              // CT_MAX_AGE=n: n + 1 regions whatever the batch size (0 = by batch duration)
     bool hand_on_jobs = true;              // CT_HAND_ON_JOBS=0: a wave finishes its own job before it suspends (A/B)
+    bool serpentine = false;               // CT_SERPENTINE=1: short launches walk their job queues alternately forwards and backwards
     // work queue of the persistent kernel (rebuilt when the camera moves)
     float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
     float4 *d_advance = nullptr;      // per pixel: pre-walked prefix of the primary march (MARCH estimator)
@@ -756,6 +757,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     if (h->exchange) {
         h->continuation = false;   // (the exchange kernels run every path to its end)
     }
+    if (const char *e = getenv("CT_SERPENTINE")) {
+        h->serpentine = atoi(e) != 0;
+    }
     if (const char *e = getenv("CT_HAND_ON_JOBS")) {
         h->hand_on_jobs = atoi(e) != 0;
     }
@@ -1327,6 +1331,9 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     ba.queue = sl.queue;
     ba.counters = h->d_counters;
     ba.stats = h->d_counters + kCounterCount + 1;
+    if (suspend && short_batch(h, S) && h->serpentine) {
+        ba.reverse = (uint32_t)(h->launch_no & 1u);
+    }
     const int buf_out = (int)(h->launch_no & 1u), buf_in = buf_out ^ 1;
     if (h->cont_live) {
         ba.cont_in = h->cont[buf_in];

@@ -50,6 +50,8 @@ struct BatchArgs {
     // once (a launch cannot be shorter than its deepest path).  A wave drains the shared queue,
     // then the queue of the XCD it runs on, then the following ones (work stealing).
     uint32_t q_begin[kQueues + 2];
+    uint32_t reverse;          // 1 = every queue is walked from its end (short launches alternate: the sweep over the image
+                               // turns round where the previous launch stopped, whose paths this one resumes)
     uint32_t first_subframe;   // 1-based subframeId of slice 0
     uint32_t S;
     uint32_t *queue;           // kQueueWords words, zero before launch: kQueues + 1 work counters, the flag

@@ -844,8 +844,8 @@ CT_DEV bool take_job(const BatchArgs &ba, uint32_t lane, uint32_t &q_cur, uint32
             }
             j = __builtin_amdgcn_readfirstlane(j);
             if (j < end - begin) {
-                job = begin + j;
-                if (job + 1u == ba.n_jobs && lane == 0) {
+                job = ba.reverse ? end - 1u - j : begin + j;
+                if (begin + j + 1u == ba.n_jobs && lane == 0) {   // (the last job of the last queue, whichever way it is walked)
                     __atomic_store_n(ba.queue + kQueueFlag, 1u, __ATOMIC_RELAXED); // see the suspend logic
                 }
                 return true;

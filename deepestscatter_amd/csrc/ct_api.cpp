@@ -6,6 +6,7 @@
 // wrappers.  No exception leaves this file and nothing here falls back to a CPU path: if
 // HIP or the device is missing every entry point reports CT_E_NODEVICE / CT_E_HIP.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -63,6 +64,8 @@ struct CtHandle_ {
         bool accumulated = false;          // its accumulate kernel has been enqueued (ev_acc0/1 valid)
         bool awaits_accumulate = false;    // launched with suspension: A(k) is still to be enqueued
         uint32_t first = 0, S = 0;
+        uint32_t rank_base = 0, groups = 0;   // the chunk of pixel groups this launch renders (places in the job order)
+        bool with_misses = false;          // its accumulate kernel also accounts for the pixels that miss the box (once per batch)
     };
     Slot slots[kMaxRegions];
     int n_regions = 2;                     // regions of the scratch in use
@@ -74,6 +77,7 @@ struct CtHandle_ {
     float4 *d_frames_all = nullptr;        // the whole per-sample scratch
     size_t frames_total = 0;               // float4 allocated
     size_t slot_capacity = 0;              // float4 per region
+    uint64_t scratch_cap_bytes = 0;        // 0 = CT_SCRATCH_GIB / the default; else what an out-of-memory allocation left us with
     uint32_t layout_S = 0;                 // batch size the regions were laid out for
     uint32_t *left[2] = { nullptr, nullptr }; // job remainders handed on the same way (BatchArgs::left_out)
     size_t left_capacity = 0;              // entries per buffer: one per wave
@@ -94,6 +98,14 @@ struct CtHandle_ {
     uint32_t n_groups = 0, groups_capacity = 0;
     uint32_t n_jobs = 0, jobs_capacity = 0, jobs_S = 0;
     bool jobs_brief = false;          // the list was laid out for short launches (short_batch)
+    // The job list is built chunk by chunk: a chunk is a contiguous piece of `chunk_groups` groups of the cost-sorted
+    // group order, and a launch renders all S subframes of ONE chunk into a scratch region of chunk_groups * 64 columns --
+    // so the per-sample scratch does not have to hold the whole frame, while a launch still works through a few pixel groups at
+    // a time for all their subframes (what keeps its paths close together in the volume; cutting a batch by SUBFRAMES
+    // instead makes every launch sweep the whole image and costs 9-14 %).
+    uint32_t chunk_groups = 0, n_chunks = 0;
+    std::vector<std::array<uint32_t, kQueues + 2>> chunk_q_begin;   // per chunk: job ranges of the queues (absolute indices)
+    uint32_t *d_group_rank = nullptr, *d_group_order = nullptr;     // place of a group in the job order / the group at a place
     uint32_t jobs_hint = 0;           // batch size the caller asked for last (job lists are built for it)
     // subframes per job at most (cheap groups), and the bounces (x cost unit) a job's lane is expected to run.
     // Re-swept on the final kernels (8 / 256 before): +4.3 % at 512^3, +5.6 % at 1024^3, +2.6 % at 256^3, +1.3 % DELTA
@@ -284,7 +296,7 @@ static void release(CtHandle h)
         hipStreamSynchronize(h->stream);
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
-                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_job_group, h->d_job_sub, h->d_queue,
+                     h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_group_rank, h->d_group_order, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
         if (p) {
@@ -956,8 +968,16 @@ static int rebuild_queue(CtHandle h)
             }
         }
         h->d_pixels = h->d_cost = nullptr;
+        for (void *p : { (void *)h->d_group_rank, (void *)h->d_group_order }) {
+            if (p) {
+                HIPCHK(h, hipFree(p));
+            }
+        }
+        h->d_group_rank = h->d_group_order = nullptr;
         HIPCHK(h, dmalloc(&h->d_pixels, (size_t)h->n_groups * 64));
         HIPCHK(h, dmalloc(&h->d_cost, 2 * (size_t)h->n_groups));
+        HIPCHK(h, dmalloc(&h->d_group_rank, (size_t)h->n_groups));
+        HIPCHK(h, dmalloc(&h->d_group_order, (size_t)h->n_groups));
         h->groups_capacity = h->n_groups;
     }
     h->group_order.resize(h->n_groups);
@@ -991,9 +1011,10 @@ static bool short_batch(CtHandle h, uint32_t S)
 // Job list for batches of S subframes.  A job is (group, subframe range); its length is chosen
 // so that a job's expected serial work per lane stays bounded: groups whose paths are deep get
 // one-subframe jobs, cheap groups up to 16 subframes per job (Handle::job_max, job_work).
-static int build_jobs(CtHandle h, uint32_t S)
+static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
 {
-    if (h->jobs_S >= S && h->jobs_brief == short_batch(h, S)) {
+    chunk_groups = std::max(1u, std::min(chunk_groups, std::max(h->n_groups, 1u)));
+    if (h->jobs_S >= S && h->jobs_brief == short_batch(h, S) && h->chunk_groups == chunk_groups) {
         return CT_OK; // a list for a larger batch serves a smaller one (the kernel clips the jobs)
     }
     S = std::max(S, h->jobs_hint);
@@ -1038,32 +1059,57 @@ static int build_jobs(CtHandle h, uint32_t S)
     jg.reserve((size_t)h->n_groups * ((S + 7) / 8));
     js.reserve(jg.capacity());
     std::vector<double> q_weight(kQueues + 1, 0.0);
-    for (uint32_t x = 0; x <= (uint32_t)kQueues; x++) {
-        h->q_begin[x] = (uint32_t)jg.size();
-        for (uint32_t g : h->group_order) {
-            if (queue_of[g] != x) {
-                continue;
-            }
-            const float d = h->group_depth[g];
-            q_weight[x] += (double)d + unit;
-            uint32_t len = h->job_max;
-            if (d > 0.f) {
-                len = (uint32_t)std::min((float)h->job_max, std::max(1.f, job_work * unit / d));
-            }
-            for (uint32_t s0 = 0; s0 < S; s0 += len) {
-                jg.push_back(g);
-                js.push_back(s0 | (std::min(len, S - s0) << 16));
+    // chunk by chunk (a contiguous piece of the group order each), and within a chunk queue by queue
+    const uint32_t n_chunks = h->n_groups ? (h->n_groups + chunk_groups - 1) / chunk_groups : 1u;
+    h->chunk_q_begin.assign(n_chunks, std::array<uint32_t, kQueues + 2>{});
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        const uint32_t r0 = c * chunk_groups, r1 = std::min(h->n_groups, r0 + chunk_groups);
+        for (uint32_t x = 0; x <= (uint32_t)kQueues; x++) {
+            h->chunk_q_begin[c][x] = (uint32_t)jg.size();
+            for (uint32_t r = r0; r < r1; r++) {
+                const uint32_t g = h->group_order[r];
+                if (queue_of[g] != x) {
+                    continue;
+                }
+                const float d = h->group_depth[g];
+                q_weight[x] += (double)d + unit;
+                uint32_t len = h->job_max;
+                if (d > 0.f) {
+                    len = (uint32_t)std::min((float)h->job_max, std::max(1.f, job_work * unit / d));
+                }
+                for (uint32_t s0 = 0; s0 < S; s0 += len) {
+                    jg.push_back(g);
+                    js.push_back(s0 | (std::min(len, S - s0) << 16));
+                }
             }
         }
+        h->chunk_q_begin[c][kQueues + 1] = (uint32_t)jg.size();
     }
-    h->q_begin[kQueues + 1] = (uint32_t)jg.size();
+    for (int x = 0; x <= kQueues + 1; x++) {
+        h->q_begin[x] = h->chunk_q_begin[0][x];
+    }
     if (getenv("CT_STATS")) {
-        fprintf(stderr, "[cloudtrace] job queues (S=%u):", S);
+        fprintf(stderr, "[cloudtrace] job queues (S=%u, %u chunk(s) of %u groups):", S, n_chunks, chunk_groups);
         for (int x = 0; x <= kQueues; x++) {
-            fprintf(stderr, " q%d jobs %u weight %.0f;", x, h->q_begin[x + 1] - h->q_begin[x], q_weight[x]);
+            fprintf(stderr, " q%d weight %.0f;", x, q_weight[x]);
         }
         fprintf(stderr, "\n");
     }
+    {
+        // the job order itself, both ways: where a group's results go in its chunk's scratch, and whose a column is
+        std::vector<uint32_t> rank(h->n_groups);
+        for (uint32_t r = 0; r < h->n_groups; r++) {
+            rank[h->group_order[r]] = r;
+        }
+        if (h->n_groups) {
+            HIPCHK(h, hipMemcpyAsync(h->d_group_rank, rank.data(), rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->d_group_order, h->group_order.data(), h->group_order.size() * sizeof(uint32_t),
+                                     hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));   // (`rank` dies at the end of this block)
+        }
+    }
+    h->chunk_groups = chunk_groups;
+    h->n_chunks = n_chunks;
     // (nq == 1: everything sits in queue 0 and the other XCDs' waves steal from it -- one global
     // cost-sorted list, the behaviour before the queues were split)
     h->n_jobs = (uint32_t)jg.size();
@@ -1148,34 +1194,37 @@ static int tune_order(CtHandle h, uint32_t measured_subframes)
     return CT_OK;
 }
 
-// Entries of one subframe in the batch scratch: the padded pixel list (compact) or the frame (simple).
+// Entries of one subframe in the batch scratch: the columns of a chunk's pixel groups (compact) or the frame (simple).
 static size_t frame_stride(CtHandle h)
 {
     if (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) {
         return (size_t)h->scene.width * h->scene.height;
     }
-    return (size_t)h->n_groups * 64;
+    return (size_t)std::max(h->chunk_groups, 1u) * 64;
 }
 
 // How many regions a batch of S subframes should have: enough launches between a batch and its accumulate kernel that
 // no path of it is still running -- a path needs up to ~10 ms (2000 bounces) of running time, a launch lasts about as long
 // as its samples take at ~3 Gsamples/s -- but never more than the budget holds.
-static int wanted_regions(CtHandle h, uint32_t S, uint64_t budget_float4)
+static int wanted_regions(CtHandle h, uint32_t S, uint64_t need, uint64_t budget_float4)
 {
     int r;
     if (h->max_age_override > 0) {
         r = h->max_age_override + 1;
     } else {
-        const double est_ms = std::max(0.05, (double)S * (double)std::max<uint64_t>(h->hit_pixels, 1) / 3.0e6);
+        const double est_ms = std::max(0.05, (double)need / 3.0e6);
         r = 1 + (int)std::ceil(15.0 / est_ms);
     }
-    const uint64_t need = std::max<uint64_t>((uint64_t)S * frame_stride(h), 1);
-    r = (int)std::min<uint64_t>((uint64_t)r, std::max<uint64_t>(budget_float4 / need, 2));
+    (void)S;
+    r = (int)std::min<uint64_t>((uint64_t)r, std::max<uint64_t>(budget_float4 / std::max<uint64_t>(need, 1), 2));
     return std::min(CtHandle_::kMaxRegions, std::max(2, r));
 }
 
-static uint64_t scratch_slot_bytes()
+static uint64_t scratch_slot_bytes(CtHandle h)
 {
+    if (h && h->scratch_cap_bytes) {
+        return h->scratch_cap_bytes;   // (the device could not give more: ensure_frames failed with less)
+    }
     // CT_SCRATCH_GIB sets the size of one of the two regions a long batch uses.  Default 16: the 1024-spp job of a 1024^2
     // frame is then ONE launch, 14 GB, instead of two of 512 -- a launch costs a few ms besides its samples -- and 28 GB of
     // scratch are a tenth of this GPU's memory.  Allocated as needed; a device that cannot give that much gets less (below).
@@ -1183,20 +1232,63 @@ static uint64_t scratch_slot_bytes()
     if (const char *e = getenv("CT_SCRATCH_GIB")) {
         slot_bytes = (uint64_t)std::min(64, std::max(1, atoi(e))) << 30;
     }
+    if (const char *e = getenv("CT_SCRATCH_MIB")) {   // (tests: chunks of a few pixel groups on small frames)
+        slot_bytes = (uint64_t)std::min(65536, std::max(1, atoi(e))) << 20;
+    }
     return slot_bytes;
 }
 
-// The per-sample scratch laid out for batches of S subframes: regions of S * stride entries each.  Nothing may be in flight
-// when the layout changes (the caller has flushed).
+// How many pixel groups a launch of S subframes renders at once: what one scratch region holds (all of them when it can).
+static uint32_t groups_per_chunk(CtHandle h, uint32_t S)
+{
+    if (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) {
+        return std::max(h->n_groups, 1u);
+    }
+    const uint64_t region = scratch_slot_bytes(h) / sizeof(float4);
+    // (two regions at least, and result indices are 32 bits)
+    const uint64_t cap = std::min<uint64_t>(region, 0xffffffffull / 2);
+    const uint64_t g = cap / ((uint64_t)std::max(S, 1u) * 64);
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, std::max(h->n_groups, 1u)));
+}
+
+// At least `total` float4 of per-sample scratch (nothing may be in flight when it grows: the caller has flushed).
+static int reserve_frames(CtHandle h, size_t total)
+{
+    if (total <= h->frames_total) {
+        return CT_OK;
+    }
+    if (h->d_frames_all) {
+        HIPCHK(h, hipFree(h->d_frames_all));
+        h->d_frames_all = nullptr;
+        h->frames_total = 0;
+        h->slot_capacity = 0;
+    }
+    const hipError_t e = dmalloc(&h->d_frames_all, total);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        h->d_frames_all = nullptr;
+        return fail(h, e == hipErrorOutOfMemory ? CT_E_NOMEM : CT_E_HIP, "per-sample scratch of %.1f GB: %s", (double)total * 16e-9,
+                    hipGetErrorString(e));
+    }
+    // touch it now: the first launch that writes a fresh part of a large allocation has been seen to
+    // take 30 ms longer (measured on the 3.5 GB scratch of a 256-subframe batch)
+    HIPCHK(h, hipMemsetAsync(h->d_frames_all, 0, total * sizeof(float4), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->frames_total = total;
+    return CT_OK;
+}
+
+// The per-sample scratch laid out for launches of S subframes over chunks of h->chunk_groups pixel groups: regions of
+// S * stride entries each.  Nothing may be in flight when the layout changes (the caller has flushed).
 static int ensure_frames(CtHandle h, uint32_t S, bool relayout)
 {
     const size_t need = std::max<size_t>((size_t)S * frame_stride(h), 1);
     if (!relayout && need <= h->slot_capacity) {
         return CT_OK;   // (a waited-for batch, the cost-measuring launch: any region that is large enough will do)
     }
-    const uint64_t budget = 2 * scratch_slot_bytes() / sizeof(float4);
+    const uint64_t budget = 2 * scratch_slot_bytes(h) / sizeof(float4);
     // (a waited-for batch needs one region; the others are allocated when batches are first enqueued)
-    const int regions = relayout ? wanted_regions(h, S, std::max<uint64_t>(budget, 2 * need)) : 1;
+    const int regions = relayout ? wanted_regions(h, S, need, std::max<uint64_t>(budget, 2 * need)) : 1;
     size_t total = (size_t)regions * need;
     if (total > 0xffffffffull) {
         if ((relayout ? 2 : 1) * need > 0xffffffffull) {
@@ -1204,25 +1296,11 @@ static int ensure_frames(CtHandle h, uint32_t S, bool relayout)
         }
         total = (0xffffffffull / need) * need;
     }
-    if (total > h->frames_total) {
-        if (h->d_frames_all) {
-            HIPCHK(h, hipFree(h->d_frames_all));
-            h->d_frames_all = nullptr;
-            h->frames_total = 0;
-            h->slot_capacity = 0;
+    {
+        const int rc = reserve_frames(h, total);
+        if (rc != CT_OK) {
+            return rc;
         }
-        const hipError_t e = dmalloc(&h->d_frames_all, total);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            h->d_frames_all = nullptr;
-            return fail(h, e == hipErrorOutOfMemory ? CT_E_NOMEM : CT_E_HIP, "per-sample scratch of %.1f GB: %s", (double)total * 16e-9,
-                        hipGetErrorString(e));
-        }
-        // touch it now: the first launch that writes a fresh part of a large allocation has been seen to
-        // take 30 ms longer (measured on the 3.5 GB scratch of a 256-subframe batch)
-        HIPCHK(h, hipMemsetAsync(h->d_frames_all, 0, total * sizeof(float4), h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->frames_total = total;
     }
     h->slot_capacity = need;
     h->n_regions = (int)std::min<size_t>((size_t)regions, h->frames_total / need);
@@ -1269,9 +1347,9 @@ static int enqueue_accumulate(CtHandle h, CtHandle_::Slot &sl, const float4 *fra
         HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width, h->scene.height,
                                           h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
     } else {
-        HIPCHK(h, launch_accumulate_list(frames, h->n_groups * 64u, h->d_pixels, h->n_groups * 64u, h->d_primary,
-                                         h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width, h->scene.height,
-                                         h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
+        HIPCHK(h, launch_accumulate_list(frames, (uint32_t)frame_stride(h), h->d_pixels, sl.groups * 64u, h->d_group_order, sl.rank_base,
+                                         sl.with_misses, h->d_primary, h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width,
+                                         h->scene.height, h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
     }
     HIPCHK(h, hipEventRecord(sl.ev_acc1, h->stream));
     sl.accumulated = true;
@@ -1305,27 +1383,34 @@ static int launch_estimator(CtHandle h, const BatchArgs &ba)
 // surviving paths to the next one and the batch's accumulate kernel follows the launch that is max_age = n_regions - 1
 // batches younger; the paths the previous launch suspended are resumed in any case.  Does not wait.
 static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t first, uint32_t S, bool accumulate,
-                        bool suspend)
+                        bool suspend, uint32_t chunk)
 {
     CtHandle_::Slot &sl = h->slots[slot];
     const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
     const bool dense = dense_frames != nullptr;
     const uint32_t max_age = (uint32_t)(h->n_regions - 1);
+    const uint32_t rank_base = chunk * h->chunk_groups;
+    const uint32_t chunk_n = h->n_groups > rank_base ? std::min(h->chunk_groups, h->n_groups - rank_base) : 0u;
     BatchArgs ba{};
     ba.frames = dense ? dense_frames : (simple ? slot_frames(h, slot) : h->d_frames_all);
-    ba.frame_stride = (simple || dense) ? 0u : h->n_groups * 64u;
+    ba.frame_stride = (simple || dense) ? 0u : (uint32_t)frame_stride(h);
     ba.out_offset = (simple || dense) ? 0u : (uint32_t)((size_t)slot * h->slot_capacity);
     ba.primary = h->d_primary;
     ba.advance = h->no_advance ? nullptr : h->d_advance;
     ba.pixels = h->d_pixels;
+    ba.group_rank = (simple || dense) ? nullptr : h->d_group_rank;
+    ba.rank_base = rank_base;
     ba.job_group = h->d_job_group;
     ba.job_sub = h->d_job_sub;
     ba.cost = h->order_tuned ? nullptr : h->d_cost;
     ba.cost_max = h->order_tuned ? nullptr : h->d_cost + h->n_groups;
-    ba.n_jobs = h->n_jobs;
+    static const std::array<uint32_t, kQueues + 2> no_jobs{};
+    const auto &qb = chunk < h->chunk_q_begin.size() ? h->chunk_q_begin[chunk] : no_jobs;   // (the simple kernel has no job list)
+    ba.n_jobs = qb[kQueues + 1];            // (absolute index of the chunk's end: the job that raises the "list empty" flag)
     for (int x = 0; x <= kQueues + 1; x++) {
-        ba.q_begin[x] = h->q_begin[x];
+        ba.q_begin[x] = qb[x];
     }
+    const uint32_t chunk_jobs = qb[kQueues + 1] - qb[0];
     ba.first_subframe = first;
     ba.S = S;
     ba.queue = sl.queue;
@@ -1363,11 +1448,13 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     if (h->debug_invariants && !simple && !dense && h->n_groups != 0) {
         // NaNs (with a NaN alpha) wherever this batch is going to write: a sample that is never written cannot
         // pass for the one an earlier batch left there
-        HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)slot_frames(h, slot), 0x7fc0deadu, (size_t)S * h->n_groups * 64u * 4u,
+        HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)slot_frames(h, slot), 0x7fc0deadu, (size_t)S * frame_stride(h) * 4u,
                                     h->stream));
     }
     HIPCHK(h, hipEventRecord(sl.ev_start, h->stream));
     if (simple) {
+        h->host_paths += h->own_pixels * S;
+        h->host_hits += h->hit_pixels * S;
         for (uint32_t s = 0; s < S; s++) {
             BatchArgs one = ba;
             one.frames = ba.frames + (size_t)s * h->scene.width * h->scene.height;
@@ -1376,21 +1463,31 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
             HIPCHK(h, launch_render_simple(h->dev, one, h->scene.shard_index, h->scene.shard_count, h->stream));
         }
     } else {
-        if (h->n_jobs != 0 || ba.cont_in) {
+        if (chunk_jobs != 0 || ba.cont_in) {
             const int rc = launch_estimator(h, ba);
             if (rc != CT_OK) {
                 return rc;
             }
         }
-        h->host_paths += h->own_pixels * S;
-        h->host_hits += h->hit_pixels * S;
-        h->iv_expected_dealt += h->hit_pixels * S;
+        // (every group is full but the last one of the pixel list, which padding completes; it sits somewhere in the job order)
+        uint64_t chunk_hits = 0;
+        for (uint32_t r = rank_base; r < rank_base + chunk_n; r++) {
+            chunk_hits += (h->group_order[r] + 1u == h->n_groups) ? 64u - (uint64_t)((uint64_t)h->n_groups * 64u - h->hit_pixels) : 64u;
+        }
+        if (chunk == 0) {
+            h->host_paths += h->own_pixels * S;
+        }
+        h->host_hits += chunk_hits * S;
+        h->iv_expected_dealt += chunk_hits * S;
     }
     HIPCHK(h, hipEventRecord(sl.ev_done, h->stream));
     h->launch_no += 1;
     h->cont_live = suspend && !simple;
     sl.first = first;
     sl.S = S;
+    sl.rank_base = rank_base;
+    sl.groups = chunk_n;
+    sl.with_misses = chunk == 0;
     sl.pending = true;
     sl.accumulated = false;
     sl.awaits_accumulate = false;
@@ -1447,7 +1544,7 @@ static int flush(CtHandle h)
     if (h->cont_live) {
         BatchArgs ba{};
         ba.frames = h->d_frames_all;
-        ba.frame_stride = h->n_groups * 64u;
+        ba.frame_stride = (uint32_t)frame_stride(h);   // (unused: resumed paths and handed-on jobs carry their own places)
         ba.primary = h->d_primary;
         ba.advance = h->no_advance ? nullptr : h->d_advance;
         ba.pixels = h->d_pixels;
@@ -1506,35 +1603,46 @@ static int prepare_batches(CtHandle h, uint32_t S)
 {
     const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
     if (simple) {
+        h->chunk_groups = std::max(h->n_groups, 1u);
+        h->n_chunks = 1;
         return CT_OK;
     }
-    if (h->queue_dirty || h->jobs_S < S || h->jobs_brief != short_batch(h, S)) {
+    if (h->queue_dirty) {
         int rc = flush(h);
-        if (rc == CT_OK && h->queue_dirty) {
+        if (rc == CT_OK) {
             rc = rebuild_queue(h);
         }
-        if (rc == CT_OK) {
-            rc = build_jobs(h, S);
+        if (rc != CT_OK) {
+            return rc;
         }
-        return rc;
+    }
+    const uint32_t want = groups_per_chunk(h, S);
+    if (h->jobs_S < S || h->jobs_brief != short_batch(h, S) || h->chunk_groups != want || h->chunk_q_begin.empty()) {
+        const int rc = flush(h);   // the job list (and with it the layout of the scratch) changes: nothing may be in flight
+        return rc == CT_OK ? build_jobs(h, S, want) : rc;
     }
     return CT_OK;
 }
 
-// One launch of the estimator over S subframes (+ optional accumulate), waited for.  `dense_frames` is
-// the frame buffer of ct_render_subframe or NULL for the batch scratch.
+// One batch of S subframes (every chunk of the pixel groups, + optional accumulate), waited for, every path run to its
+// end.  `dense_frames` is the frame buffer of ct_render_subframe or NULL for the batch scratch.
 static int run_batch(CtHandle h, float4 *dense_frames, uint32_t first, uint32_t S, bool accumulate)
 {
     int rc = flush(h);
     if (rc == CT_OK) {
         rc = prepare_batches(h, S);
     }
+    if (rc == CT_OK && !dense_frames) {
+        rc = ensure_frames(h, S, false);
+    }
     if (rc != CT_OK) {
         return rc;
     }
-    rc = submit_batch(h, 0, dense_frames, first, S, accumulate, false);
-    if (rc == CT_OK) {
-        rc = collect(h, h->slots[0]);
+    for (uint32_t c = 0; c < std::max(h->n_chunks, 1u) && rc == CT_OK; c++) {
+        rc = submit_batch(h, 0, dense_frames, first, S, accumulate, false, c);
+        if (rc == CT_OK) {
+            rc = collect(h, h->slots[0]);
+        }
     }
     if (rc != CT_OK) {
         return rc;
@@ -1612,73 +1720,90 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             return rc;
         }
     }
-    // split so that a region of the scratch stays within its size, scratch indices fit 32 bits and the subframe offset fits
-    // the 16 bits of job_sub
-    const uint64_t stride = std::max<uint64_t>(frame_stride(h), 1);
-    uint64_t cap = std::min<uint64_t>(scratch_slot_bytes() / (stride * sizeof(float4)), 0xffffffffull / (2 * stride));
-    cap = std::max<uint64_t>(std::min<uint64_t>(cap, 0xffffull), 1);
+    // A call is cut by SUBFRAMES only where it must be (the subframe offset of a job has 16 bits); what does not fit the
+    // scratch is cut by PIXEL GROUPS: every launch renders all the subframes of one chunk of groups (prepare_batches).
+    const uint64_t cap = 0xffffull;
     uint32_t done = 0;
     // job lists are built for the size of the call's batches, not for the remainder that follows the short
     // cost-measuring launch (the next call of the same size would rebuild them)
     h->jobs_hint = (uint32_t)((count + (count + cap - 1) / cap - 1) / ((count + cap - 1) / cap));
+    if (!simple) {
+        // the scratch is sized for the call's batches now, not grown when the first of them follows the short cost-measuring
+        // launch (freeing and allocating tens of GB takes hundreds of milliseconds)
+        for (;;) {
+            const uint32_t gc = groups_per_chunk(h, h->jobs_hint);
+            const size_t need = (size_t)h->jobs_hint * gc * 64;
+            const bool enqueue = !wait || gc < h->n_groups;
+            const uint64_t budget = 2 * scratch_slot_bytes(h) / sizeof(float4);
+            const size_t total = std::min<size_t>((size_t)(enqueue ? wanted_regions(h, h->jobs_hint, need, std::max<uint64_t>(budget, 2 * need)) : 1) * need,
+                                                  (0xffffffffull / std::max<size_t>(need, 1)) * need);
+            if (total <= h->frames_total) {
+                break;
+            }
+            int rc = flush(h);
+            if (rc == CT_OK) {
+                rc = reserve_frames(h, total);
+            }
+            if (rc == CT_E_NOMEM && scratch_slot_bytes(h) > (64ull << 20)) {
+                h->scratch_cap_bytes = scratch_slot_bytes(h) / 2;   // the device cannot give that much: smaller chunks
+                continue;
+            }
+            if (rc != CT_OK) {
+                return rc;
+            }
+            break;
+        }
+    }
     while (done < count) {
-        // what is left, cut into the fewest launches the scratch allows, all of the same size (1024 subframes at
-        // 1024^2 with 8 GiB regions, which hold 624: two launches of 512, not 624 + 400)
         const uint64_t left = count - done, parts = (left + cap - 1) / cap;
         uint32_t S = (uint32_t)((left + parts - 1) / parts);
         int rc;
         if (!simple && !h->order_tuned) {
             // the first launch of a pose measures the job costs (two atomics per path, jobs in image
             // order): it is kept short, waited for, then the order is set
-            rc = flush(h);
-            if (rc == CT_OK) {
-                rc = ensure_frames(h, S, !wait); // laid out for the batches that follow, not for this short one
-            }
-            if (rc == CT_E_NOMEM && S > 1) {
-                cap = std::max<uint64_t>(S / 2, 1);   // the device cannot give that much: more, shorter launches
-                continue;
-            }
             S = std::min(S, kTuneSubframes);
-            if (rc == CT_OK) {
-                rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
-            }
+            rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
         } else {
             const bool trace = getenv("CT_TRACE") != nullptr;
             const auto t0 = std::chrono::steady_clock::now();
             rc = prepare_batches(h, S);
+            // several chunks: they are enqueued like batches (paths pass from chunk to chunk) and a waited-for call waits at the end
+            const bool enqueue = !wait || (h->n_chunks > 1 && h->continuation && !simple);
             const size_t need = (size_t)S * frame_stride(h);
-            if (rc == CT_OK && (need > h->slot_capacity || (!wait && (S != h->layout_S || h->n_regions < 2)))) {
+            if (rc == CT_OK && (need > h->slot_capacity || (enqueue && (S != h->layout_S || h->n_regions < 2)))) {
                 rc = flush(h); // the layout of the scratch changes: nothing may be in flight
                 if (rc == CT_OK) {
-                    rc = ensure_frames(h, S, !wait);
+                    rc = ensure_frames(h, S, enqueue);
                 }
-                if (rc == CT_E_NOMEM && S > 1) {
-                    cap = std::max<uint64_t>(S / 2, 1);
+                if (rc == CT_E_NOMEM && scratch_slot_bytes(h) > (64ull << 20)) {
+                    h->scratch_cap_bytes = scratch_slot_bytes(h) / 2;   // the device cannot give that much: smaller chunks
                     continue;
                 }
             }
             const auto t1 = std::chrono::steady_clock::now();
-            if (wait) {
+            if (!enqueue) {
                 rc = rc == CT_OK ? flush(h) : rc;
-                h->next_slot = 0; // synchronous batches use one region and run every path to its end
+                h->next_slot = 0; // a synchronous batch uses one region and runs every path to its end
             }
-            const int slot = h->next_slot;
-            if (rc == CT_OK) {
-                rc = collect(h, h->slots[slot]); // book the launch that used this region n_regions batches ago
-            }
-            const auto t2 = std::chrono::steady_clock::now();
-            if (rc == CT_OK) {
-                const bool suspend = !wait && h->continuation && !simple;
-                rc = submit_batch(h, slot, nullptr, first_subframe_id + done, S, true, suspend);
-            }
-            if (trace) {
-                const auto t3 = std::chrono::steady_clock::now();
-                auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-                fprintf(stderr, "[cloudtrace] batch first=%u S=%u region %d of %d: prepare %.2f ms, slot %.2f ms, submit %.2f ms\n",
-                        first_subframe_id + done, S, slot, h->n_regions, ms(t0, t1), ms(t1, t2), ms(t2, t3));
-            }
-            if (!wait) {
-                h->next_slot = (h->next_slot + 1) % h->n_regions;
+            for (uint32_t c = 0; c < std::max(h->n_chunks, 1u) && rc == CT_OK; c++) {
+                const int slot = h->next_slot;
+                rc = collect(h, h->slots[slot]); // book the launch that used this region n_regions launches ago
+                const auto t2 = std::chrono::steady_clock::now();
+                if (rc == CT_OK) {
+                    const bool suspend = enqueue && h->continuation && !simple;
+                    rc = submit_batch(h, slot, nullptr, first_subframe_id + done, S, true, suspend, c);
+                }
+                if (trace) {
+                    const auto t3 = std::chrono::steady_clock::now();
+                    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                    fprintf(stderr, "[cloudtrace] batch first=%u S=%u chunk %u of %u, region %d of %d: prepare %.2f ms, slot %.2f ms, submit %.2f ms\n",
+                            first_subframe_id + done, S, c, h->n_chunks, slot, h->n_regions, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+                }
+                if (enqueue) {
+                    h->next_slot = (h->next_slot + 1) % h->n_regions;
+                } else if (rc == CT_OK) {
+                    rc = collect(h, h->slots[slot]);
+                }
             }
         }
         if (rc != CT_OK) {

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kXThreads) void render_delta_x_kernel(DevScene sc, 
                             }
                             const float4 p0 = ba.primary[2 * (size_t)pixel];
                             const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                            const uint32_t out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + (g * 64u + l) : pixel;
+                            const uint32_t out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + group_column(ba, g) + l : pixel;
                             const f3 pos = mk3(p0.x, p0.y, p0.z);
                             const bool hit = p0.w != 0.f;
                             dir = mk3(p1.x, p1.y, p1.z);
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(kXThreads) void render_delta_w_kernel(DevScene sc, 
                             }
                             const float4 p0 = ba.primary[2 * (size_t)pixel];
                             const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                            const uint32_t out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + (g * 64u + l) : pixel;
+                            const uint32_t out_idx = ba.frame_stride ? ba.out_offset + s * ba.frame_stride + group_column(ba, g) + l : pixel;
                             const f3 pos = mk3(p0.x, p0.y, p0.z);
                             const bool hit = p0.w != 0.f;
                             dir = mk3(p1.x, p1.y, p1.z);

@@ -33,6 +33,11 @@ struct BatchArgs {
                                // (MARCH, primary_advance_kernel) or 4 (DELTA, primary_advance_delta_kernel);
                                // NULL = start at the entry point
     const uint32_t *pixels;    // this shard's box-hitting pixels, 64 per group, 0xffffffff padded
+    // A launch may cover only a CHUNK of the pixel groups (all S subframes of each): the scratch then has a column of 64
+    // entries per group of the chunk, group g's at (group_rank[g] - rank_base) * 64 -- group_rank = the group's place in the
+    // cost-sorted order the job list is built in, of which a chunk is a contiguous piece.  NULL: column g * 64 (every group).
+    const uint32_t *group_rank;
+    uint32_t rank_base;
     // job list: job j renders subframes [begin, begin+count) of pixel group job_group[j];
     // job_sub[j] = begin | count << 16.  Sorted most expensive group first, and expensive groups
     // are cut into short jobs, so the long paths start early and spread over all waves while
@@ -140,7 +145,8 @@ hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m
                                    uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
                                    uint32_t shard_count, unsigned long long *bad_samples, hipStream_t stream);
 hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, const uint32_t *pixels,
-                                  uint32_t n_entries, const float4 *primary, float4 *mean, float4 *m2,
+                                  uint32_t n_entries, const uint32_t *group_order, uint32_t rank_base, bool with_misses,
+                                  const float4 *primary, float4 *mean, float4 *m2,
                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
                                   uint32_t shard_index, uint32_t shard_count, unsigned long long *bad_samples,
                                   hipStream_t stream);

@@ -785,8 +785,15 @@ CT_DEV uint32_t xcd_id()
 // A job the previous launch handed on (BatchArgs::left_in).  Wave-uniform.
 struct JobState {
     uint32_t g, s0, next, end;   // pixel group, first subframe (relative to `first`), samples [next, end) still to start
-    uint32_t off, first, age;    // the batch's scratch offset and first subframe id; the age its samples start with
+    uint32_t base, stride;       // the group's column in its batch's scratch region (absolute index) and that region's stride
+    uint32_t first, age;         // the batch's first subframe id; the age its samples start with
 };
+
+// Where group g's 64 results of a subframe go within a subframe's row of the scratch (BatchArgs::group_rank).
+CT_DEV uint32_t group_column(const BatchArgs &ba, uint32_t g)
+{
+    return (ba.group_rank ? __builtin_amdgcn_readfirstlane(ba.group_rank[g]) - ba.rank_base : g) * 64u;
+}
 
 CT_DEV bool take_leftover(const BatchArgs &ba, uint32_t lane, bool &left_done, JobState &job)
 {
@@ -807,9 +814,10 @@ CT_DEV bool take_leftover(const BatchArgs &ba, uint32_t lane, bool &left_done, J
     job.s0 = __builtin_amdgcn_readfirstlane(r[1]);
     job.next = __builtin_amdgcn_readfirstlane(r[2]);
     job.end = __builtin_amdgcn_readfirstlane(r[3]);
-    job.off = __builtin_amdgcn_readfirstlane(r[4]);
+    job.base = __builtin_amdgcn_readfirstlane(r[4]);
     job.first = __builtin_amdgcn_readfirstlane(r[5]);
     job.age = __builtin_amdgcn_readfirstlane(r[6]);
+    job.stride = __builtin_amdgcn_readfirstlane(r[7]);
     return true;
 }
 
@@ -825,7 +833,7 @@ CT_DEV bool hand_on_job(const BatchArgs &ba, uint32_t lane, const JobState &job)
         } else {
             uint4 *r = (uint4 *)(ba.left_out + (size_t)i * kLeftWords);
             r[0] = make_uint4(job.g, job.s0, job.next, job.end);
-            r[1] = make_uint4(job.off, job.first, job.age + 1u, 0u);
+            r[1] = make_uint4(job.base, job.first, job.age + 1u, job.stride);
         }
     }
     return __builtin_amdgcn_readfirstlane(i) != 0xffffffffu;
@@ -949,7 +957,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     int state = ST_IDLE;
 
     // wave-uniform bookkeeping (lives in SGPRs): the current job and the samples left in it
-    JobState job{ 0, 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
+    JobState job{ 0, 0, 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
     bool left_done = false;
     uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
@@ -1048,7 +1056,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     job.next = 0;
                     // the list may have been built for a larger batch: clip the job to this launch's subframes
                     job.end = (job.s0 < ba.S ? min(sub >> 16, ba.S - job.s0) : 0u) * 64u;
-                    job.off = ba.out_offset;
+                    job.base = ba.out_offset + group_column(ba, job.g);
+                    job.stride = ba.frame_stride;
                     job.first = ba.first_subframe;
                     job.age = 0;
                 }
@@ -1073,7 +1082,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                         }
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                        out_idx = ba.frame_stride ? job.off + s * ba.frame_stride + (g * 64u + l) : pixel;
+                        out_idx = ba.frame_stride ? job.base + s * job.stride + l : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f; // image jobs list hitting pixels only; point tasks may miss
@@ -1732,7 +1741,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
     uint32_t seed = 0, depth = 0, out_idx = 0, group = 0;
     int state = ST_IDLE;
 
-    JobState job{ 0, 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
+    JobState job{ 0, 0, 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
     bool left_done = false;
     uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
@@ -1809,7 +1818,8 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                     job.next = 0;
                     // the list may have been built for a larger batch: clip the job to this launch's subframes
                     job.end = (job.s0 < ba.S ? min(sub >> 16, ba.S - job.s0) : 0u) * 64u;
-                    job.off = ba.out_offset;
+                    job.base = ba.out_offset + group_column(ba, job.g);
+                    job.stride = ba.frame_stride;
                     job.first = ba.first_subframe;
                     job.age = 0;
                 }
@@ -1834,7 +1844,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                         }
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                        out_idx = ba.frame_stride ? job.off + s * ba.frame_stride + (g * 64u + l) : pixel;
+                        out_idx = ba.frame_stride ? job.base + s * job.stride + l : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f;
@@ -2459,6 +2469,7 @@ hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m
 // Compact form, part 1: one thread per entry of the pixel list (this shard's box-hitting pixels).
 __global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__restrict__ frames, uint32_t frame_stride,
                                                               const uint32_t *__restrict__ pixels, uint32_t n_entries,
+                                                              const uint32_t *__restrict__ group_order, uint32_t rank_base,
                                                               float4 *__restrict__ mean, float4 *__restrict__ m2,
                                                               uint32_t first_subframe, uint32_t S,
                                                               unsigned long long *__restrict__ bad_samples)
@@ -2467,7 +2478,8 @@ __global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__re
     if (e >= n_entries) {
         return;
     }
-    const uint32_t pix = pixels[e];
+    // (entry e of a chunk's scratch row belongs to the group at place rank_base + e / 64 of the job order: BatchArgs::group_rank)
+    const uint32_t pix = group_order ? pixels[group_order[rank_base + (e >> 6)] * 64u + (e & 63u)] : pixels[e];
     if (pix == 0xffffffffu) {
         return;
     }
@@ -2531,18 +2543,21 @@ __global__ __launch_bounds__(256) void accumulate_miss_kernel(const float4 *__re
 }
 
 hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, const uint32_t *pixels,
-                                  uint32_t n_entries, const float4 *primary, float4 *mean, float4 *m2,
+                                  uint32_t n_entries, const uint32_t *group_order, uint32_t rank_base, bool with_misses,
+                                  const float4 *primary, float4 *mean, float4 *m2,
                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
                                   uint32_t shard_index, uint32_t shard_count, unsigned long long *bad_samples,
                                   hipStream_t stream)
 {
     if (n_entries) {
         hipLaunchKernelGGL(accumulate_list_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, stream, frames,
-                           frame_stride, pixels, n_entries, mean, m2, first_subframe, S, bad_samples);
+                           frame_stride, pixels, n_entries, group_order, rank_base, mean, m2, first_subframe, S, bad_samples);
     }
-    const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
-    hipLaunchKernelGGL(accumulate_miss_kernel, grid, block, 0, stream, primary, mean, m2, first_subframe, S, width,
-                       height, shard_index, shard_count);
+    if (with_misses) {   // (once per batch of subframes, whatever number of chunks the pixel groups are rendered in)
+        const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
+        hipLaunchKernelGGL(accumulate_miss_kernel, grid, block, 0, stream, primary, mean, m2, first_subframe, S, width,
+                           height, shard_index, shard_count);
+    }
     return hipGetLastError();
 }
 

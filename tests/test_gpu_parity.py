@@ -1300,3 +1300,32 @@ def test_short_batches_with_repeated_suspension_are_bit_exact(estimator, max_age
     assert got[2] == want[2]
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert np.array_equal(np.asarray(screen).reshape(h, w, 4), want[3])
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_batches_cut_by_pixel_groups_are_bit_exact(estimator, monkeypatch):
+    """A batch whose samples do not fit one scratch region is rendered chunk by chunk of PIXEL GROUPS -- every launch all the
+    subframes of a piece of the cost-sorted group order, its results in columns of its own, accumulated by its own kernel --
+    with paths and job remainders passing from chunk to chunk.  1 MiB regions on a 160x160 frame: seven launches per
+    batch.  Waited-for and enqueued calls, invariants armed, against the one-launch frame bit for bit."""
+    tex = ds.make_procedural_cloud(96)
+    w = h = 160
+    ref = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+    ref.render_accumulate(1, 70)
+    want = (ref.mean(), ref.m2(), ref.counters())
+    ref.close()
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    monkeypatch.setenv("CT_SCRATCH_MIB", "1")
+    tr = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+    tr.render_accumulate(1, 16)              # the cost-measuring launch, then ...
+    tr.render_accumulate(17, 16)             # ... a waited-for batch in chunks
+    tr.render_accumulate_async(33, 16)       # enqueued batches in chunks
+    tr.render_accumulate_async(49, 16)
+    tr.render_accumulate_async(65, 6)        # (another batch size: other chunks)
+    got = (tr.mean(), tr.m2(), tr.counters())
+    iv = tr.debug_invariants()
+    tr.close()
+    assert iv["armed"] == 1 and iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+    assert iv["resumed"] == iv["suspended"] > 0
+    assert got[2] == want[2]
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])

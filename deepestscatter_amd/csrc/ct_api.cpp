@@ -121,6 +121,9 @@ struct CtHandle_ {
     float shared_depth = 1e30f;          // groups at least this deep (bounces) use the shared queue
     uint32_t regions = 128;              // image regions dealt to the per-XCD queues
     std::vector<uint32_t> group_order;   // groups, most expensive first (identity until tuned)
+    std::vector<uint32_t> job_order;     // the order the job list is built in: group_order, or its chunks interleaved (build_jobs)
+    bool chunk_interleave = false;       // CT_CHUNK_INTERLEAVE=1: every chunk is every C-th group of group_order (A/B: worse, the neighbours are gone)
+    bool chunk_morton = false;           // CT_CHUNK_MORTON=1: chunks are compact image regions (A/B)
     std::vector<float> group_depth;      // measured mean path cost per group (0 until tuned), in the
                                          // units of BatchArgs::cost
     unsigned long long host_paths = 0, host_hits = 0; // paths / box hits of the persistent path
@@ -769,6 +772,12 @@ static int create_impl(const CtScene *s, CtHandle h)
     if (h->exchange) {
         h->continuation = false;   // (the exchange kernels run every path to its end)
     }
+    if (const char *e = getenv("CT_CHUNK_INTERLEAVE")) {
+        h->chunk_interleave = atoi(e) != 0;
+    }
+    if (const char *e = getenv("CT_CHUNK_MORTON")) {
+        h->chunk_morton = atoi(e) != 0;
+    }
     if (const char *e = getenv("CT_SERPENTINE")) {
         h->serpentine = atoi(e) != 0;
     }
@@ -1061,13 +1070,37 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
     std::vector<double> q_weight(kQueues + 1, 0.0);
     // chunk by chunk (a contiguous piece of the group order each), and within a chunk queue by queue
     const uint32_t n_chunks = h->n_groups ? (h->n_groups + chunk_groups - 1) / chunk_groups : 1u;
+    if (n_chunks > 1 && h->chunk_interleave) {
+        // Every chunk gets the same mix of expensive and cheap groups (2 % of the groups make 98 % of the cost): the job order
+        // becomes places 0, C, 2C, ... of the cost-sorted order, then 1, C + 1, ..., so that a contiguous piece of it is every
+        // C-th group -- launches of equal length instead of a few long ones and many that are over before the paths they
+        // resumed have moved.
+        std::vector<uint32_t> mixed;
+        mixed.reserve(h->n_groups);
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            for (uint32_t r = c; r < h->n_groups; r += n_chunks) {
+                mixed.push_back(h->group_order[r]);
+            }
+        }
+        // (pieces must be whole chunks: with n_groups not a multiple of n_chunks the first chunks are one group longer than
+        // chunk_groups allows only if chunk_groups * n_chunks < n_groups, which the rounding above excludes)
+        h->job_order = mixed;
+    } else if (n_chunks > 1 && h->chunk_morton) {
+        // (probe: chunks = compact image regions -- the groups in tile-Morton order, which is their index order)
+        h->job_order.resize(h->n_groups);
+        for (uint32_t g = 0; g < h->n_groups; g++) {
+            h->job_order[g] = g;
+        }
+    } else {
+        h->job_order = h->group_order;
+    }
     h->chunk_q_begin.assign(n_chunks, std::array<uint32_t, kQueues + 2>{});
     for (uint32_t c = 0; c < n_chunks; c++) {
         const uint32_t r0 = c * chunk_groups, r1 = std::min(h->n_groups, r0 + chunk_groups);
         for (uint32_t x = 0; x <= (uint32_t)kQueues; x++) {
             h->chunk_q_begin[c][x] = (uint32_t)jg.size();
             for (uint32_t r = r0; r < r1; r++) {
-                const uint32_t g = h->group_order[r];
+                const uint32_t g = h->job_order[r];
                 if (queue_of[g] != x) {
                     continue;
                 }
@@ -1099,11 +1132,11 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
         // the job order itself, both ways: where a group's results go in its chunk's scratch, and whose a column is
         std::vector<uint32_t> rank(h->n_groups);
         for (uint32_t r = 0; r < h->n_groups; r++) {
-            rank[h->group_order[r]] = r;
+            rank[h->job_order[r]] = r;
         }
         if (h->n_groups) {
             HIPCHK(h, hipMemcpyAsync(h->d_group_rank, rank.data(), rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(h->d_group_order, h->group_order.data(), h->group_order.size() * sizeof(uint32_t),
+            HIPCHK(h, hipMemcpyAsync(h->d_group_order, h->job_order.data(), h->job_order.size() * sizeof(uint32_t),
                                      hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));   // (`rank` dies at the end of this block)
         }
@@ -1472,7 +1505,7 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         // (every group is full but the last one of the pixel list, which padding completes; it sits somewhere in the job order)
         uint64_t chunk_hits = 0;
         for (uint32_t r = rank_base; r < rank_base + chunk_n; r++) {
-            chunk_hits += (h->group_order[r] + 1u == h->n_groups) ? 64u - (uint64_t)((uint64_t)h->n_groups * 64u - h->hit_pixels) : 64u;
+            chunk_hits += (h->job_order[r] + 1u == h->n_groups) ? 64u - (uint64_t)((uint64_t)h->n_groups * 64u - h->hit_pixels) : 64u;
         }
         if (chunk == 0) {
             h->host_paths += h->own_pixels * S;

@@ -124,6 +124,7 @@ struct CtHandle_ {
     std::vector<uint32_t> job_order;     // the order the job list is built in: group_order, or its chunks interleaved (build_jobs)
     bool chunk_interleave = false;       // CT_CHUNK_INTERLEAVE=1: every chunk is every C-th group of group_order (A/B: worse, the neighbours are gone)
     bool chunk_morton = false;           // CT_CHUNK_MORTON=1: chunks are compact image regions (A/B)
+    bool tile_hilbert = false;           // CT_TILE_ORDER=hilbert: pixel groups along a Hilbert curve instead of Morton order (A/B)
     std::vector<float> group_depth;      // measured mean path cost per group (0 until tuned), in the
                                          // units of BatchArgs::cost
     unsigned long long host_paths = 0, host_hits = 0; // paths / box hits of the persistent path
@@ -281,6 +282,28 @@ static uint32_t morton2(uint32_t x, uint32_t y)
         return v;
     };
     return spread(x) | (spread(y) << 1);
+}
+
+// Position of tile (x, y) along a Hilbert curve over a 2^15 x 2^15 grid (the standard xy2d): like the Morton index a
+// locality-preserving order of the tiles, but without its jumps -- consecutive tiles are always neighbours.
+static uint32_t hilbert2(uint32_t x, uint32_t y)
+{
+    const uint32_t n = 1u << 15;
+    uint32_t d = 0;
+    for (uint32_t s = n / 2; s > 0; s /= 2) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) {
+                x = n - 1u - x;
+                y = n - 1u - y;
+            }
+            const uint32_t t = x;
+            x = y;
+            y = t;
+        }
+    }
+    return d;
 }
 
 template <typename T>
@@ -775,6 +798,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     if (const char *e = getenv("CT_CHUNK_INTERLEAVE")) {
         h->chunk_interleave = atoi(e) != 0;
     }
+    if (const char *e = getenv("CT_TILE_ORDER")) {
+        h->tile_hilbert = strcmp(e, "hilbert") == 0;
+    }
     if (const char *e = getenv("CT_CHUNK_MORTON")) {
         h->chunk_morton = atoi(e) != 0;
     }
@@ -943,7 +969,7 @@ static int rebuild_queue(CtHandle h)
     for (uint32_t ty = 0; ty < tiles_y; ty++) {
         for (uint32_t tx = 0; tx < tiles_x; tx++) {
             if (tile_owner(tx, ty, h->scene.shard_count) == h->scene.shard_index) {
-                tiles.emplace_back(morton2(tx, ty), ty * tiles_x + tx);
+                tiles.emplace_back(h->tile_hilbert ? hilbert2(tx, ty) : morton2(tx, ty), ty * tiles_x + tx);
             }
         }
     }
@@ -1380,7 +1406,8 @@ static int enqueue_accumulate(CtHandle h, CtHandle_::Slot &sl, const float4 *fra
         HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width, h->scene.height,
                                           h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
     } else {
-        HIPCHK(h, launch_accumulate_list(frames, (uint32_t)frame_stride(h), h->d_pixels, sl.groups * 64u, h->d_group_order, sl.rank_base,
+        HIPCHK(h, launch_accumulate_list(frames, (uint32_t)frame_stride(h), h->d_pixels, sl.groups * 64u,
+                                         h->n_chunks <= 1 ? nullptr : h->d_group_order, sl.rank_base,
                                          sl.with_misses, h->d_primary, h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width,
                                          h->scene.height, h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
     }
@@ -1431,7 +1458,7 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     ba.primary = h->d_primary;
     ba.advance = h->no_advance ? nullptr : h->d_advance;
     ba.pixels = h->d_pixels;
-    ba.group_rank = (simple || dense) ? nullptr : h->d_group_rank;
+    ba.group_rank = (simple || dense || h->n_chunks <= 1) ? nullptr : h->d_group_rank;   // (one chunk: column g * 64, as ever)
     ba.rank_base = rank_base;
     ba.job_group = h->d_job_group;
     ba.job_sub = h->d_job_sub;

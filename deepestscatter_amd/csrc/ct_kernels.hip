@@ -784,10 +784,11 @@ CT_DEV uint32_t xcd_id()
 
 // A job the previous launch handed on (BatchArgs::left_in).  Wave-uniform.
 struct JobState {
-    uint32_t g, s0, next, end;   // pixel group, first subframe (relative to `first`), samples [next, end) still to start
-    uint32_t base, stride;       // the group's column in its batch's scratch region (absolute index) and that region's stride
-    uint32_t first, age;         // the batch's first subframe id; the age its samples start with
-};
+    uint32_t g, next, end;       // pixel group; samples [next, end) still to start: sample q is lane q & 63 of the job's subframe q >> 6
+    uint32_t base;               // scratch index of the job's first subframe, lane 0 (absolute: region, row and the group's column)
+    uint32_t first;              // subframe id of the job's first subframe
+    uint32_t age;                // the age its samples start with
+};   // (six SGPRs that live through the whole scheduler loop; the scratch's row stride is the same for every job in flight)
 
 // Where group g's 64 results of a subframe go within a subframe's row of the scratch (BatchArgs::group_rank).
 CT_DEV uint32_t group_column(const BatchArgs &ba, uint32_t g)
@@ -811,13 +812,11 @@ CT_DEV bool take_leftover(const BatchArgs &ba, uint32_t lane, bool &left_done, J
     }
     const uint32_t *r = ba.left_in + (size_t)i * kLeftWords;
     job.g = __builtin_amdgcn_readfirstlane(r[0]);
-    job.s0 = __builtin_amdgcn_readfirstlane(r[1]);
-    job.next = __builtin_amdgcn_readfirstlane(r[2]);
-    job.end = __builtin_amdgcn_readfirstlane(r[3]);
-    job.base = __builtin_amdgcn_readfirstlane(r[4]);
-    job.first = __builtin_amdgcn_readfirstlane(r[5]);
-    job.age = __builtin_amdgcn_readfirstlane(r[6]);
-    job.stride = __builtin_amdgcn_readfirstlane(r[7]);
+    job.next = __builtin_amdgcn_readfirstlane(r[1]);
+    job.end = __builtin_amdgcn_readfirstlane(r[2]);
+    job.base = __builtin_amdgcn_readfirstlane(r[3]);
+    job.first = __builtin_amdgcn_readfirstlane(r[4]);
+    job.age = __builtin_amdgcn_readfirstlane(r[5]);
     return true;
 }
 
@@ -832,8 +831,8 @@ CT_DEV bool hand_on_job(const BatchArgs &ba, uint32_t lane, const JobState &job)
             i = 0xffffffffu;
         } else {
             uint4 *r = (uint4 *)(ba.left_out + (size_t)i * kLeftWords);
-            r[0] = make_uint4(job.g, job.s0, job.next, job.end);
-            r[1] = make_uint4(job.base, job.first, job.age + 1u, job.stride);
+            r[0] = make_uint4(job.g, job.next, job.end, job.base);
+            r[1] = make_uint4(job.first, job.age + 1u, 0u, 0u);
         }
     }
     return __builtin_amdgcn_readfirstlane(i) != 0xffffffffu;
@@ -957,7 +956,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     int state = ST_IDLE;
 
     // wave-uniform bookkeeping (lives in SGPRs): the current job and the samples left in it
-    JobState job{ 0, 0, 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
+    JobState job{ 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
     bool left_done = false;
     uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
@@ -1051,14 +1050,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                         st_stolen += (q_tried != 0u) ? 1u : 0u;
                     }
                     const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
+                    const uint32_t s0 = sub & 0xffffu;
                     job.g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
-                    job.s0 = sub & 0xffffu;
                     job.next = 0;
                     // the list may have been built for a larger batch: clip the job to this launch's subframes
-                    job.end = (job.s0 < ba.S ? min(sub >> 16, ba.S - job.s0) : 0u) * 64u;
-                    job.base = ba.out_offset + group_column(ba, job.g);
-                    job.stride = ba.frame_stride;
-                    job.first = ba.first_subframe;
+                    job.end = (s0 < ba.S ? min(sub >> 16, ba.S - s0) : 0u) * 64u;
+                    job.base = ba.out_offset + s0 * ba.frame_stride + group_column(ba, job.g);
+                    job.first = ba.first_subframe + s0;
                     job.age = 0;
                 }
             }
@@ -1073,7 +1071,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 const uint32_t q = job.next + rank;
                 job.next += min(n_idle, avail);
                 if (take) {
-                    const uint32_t s = job.s0 + (q >> 6), l = q & 63u;
+                    const uint32_t s = q >> 6, l = q & 63u;   // (subframe within the job, lane)
                     const uint32_t g = job.g;
                     const uint32_t pixel = ba.pixels[g * 64u + l];
                     if (pixel != 0xffffffffu) {
@@ -1082,7 +1080,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                         }
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                        out_idx = ba.frame_stride ? job.base + s * job.stride + l : pixel;
+                        out_idx = ba.frame_stride ? job.base + s * ba.frame_stride + l : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f; // image jobs list hitting pixels only; point tasks may miss
@@ -1741,7 +1739,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
     uint32_t seed = 0, depth = 0, out_idx = 0, group = 0;
     int state = ST_IDLE;
 
-    JobState job{ 0, 0, 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
+    JobState job{ 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
     bool left_done = false;
     uint32_t q_cur = (uint32_t)kQueues, q_tried = 0;
     bool drained = false;
@@ -1813,14 +1811,13 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                     drained = true;
                 } else {
                     const uint32_t sub = __builtin_amdgcn_readfirstlane(ba.job_sub[j]);
+                    const uint32_t s0 = sub & 0xffffu;
                     job.g = __builtin_amdgcn_readfirstlane(ba.job_group[j]);
-                    job.s0 = sub & 0xffffu;
                     job.next = 0;
                     // the list may have been built for a larger batch: clip the job to this launch's subframes
-                    job.end = (job.s0 < ba.S ? min(sub >> 16, ba.S - job.s0) : 0u) * 64u;
-                    job.base = ba.out_offset + group_column(ba, job.g);
-                    job.stride = ba.frame_stride;
-                    job.first = ba.first_subframe;
+                    job.end = (s0 < ba.S ? min(sub >> 16, ba.S - s0) : 0u) * 64u;
+                    job.base = ba.out_offset + s0 * ba.frame_stride + group_column(ba, job.g);
+                    job.first = ba.first_subframe + s0;
                     job.age = 0;
                 }
             }
@@ -1835,7 +1832,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                 const uint32_t q = job.next + rank;
                 job.next += min(n_idle, avail);
                 if (take) {
-                    const uint32_t s = job.s0 + (q >> 6), l = q & 63u;
+                    const uint32_t s = q >> 6, l = q & 63u;   // (subframe within the job, lane)
                     const uint32_t g = job.g;
                     const uint32_t pixel = ba.pixels[g * 64u + l];
                     if (pixel != 0xffffffffu) {
@@ -1844,7 +1841,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                         }
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
-                        out_idx = ba.frame_stride ? job.base + s * job.stride + l : pixel;
+                        out_idx = ba.frame_stride ? job.base + s * ba.frame_stride + l : pixel;
                         group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f;

@@ -135,10 +135,17 @@ def cpu_baseline(ds, tex, ins, width, height, mode, target_s):
     return out
 
 
-def progressive_leg(tr, W, H, first, spp=10, updates=100):
+def progressive_leg(tr, W, H, first, spp=10, updates=100, ahead=0):
     """The reference's cadence (Camera::render, Camera.cpp:189-214): `spp` subframes, then the display update.  Enqueued
-    batches with ct_tonemap_async behind each; paths and unstarted jobs pass from launch to launch."""
-    for _ in range(8):                                  # the ring of scratch regions and the job list for this batch size
+    batches with ct_tonemap_async behind each; paths and unstarted jobs pass from launch to launch.
+    ahead > 0: the same calls with ct_set_render_ahead(ahead) -- launches of `ahead` subframes, every call accumulating and
+    displaying its own share; warm-up and timed region are whole launches, so what is timed is what is counted."""
+    warm = 8
+    if ahead:
+        tr.set_render_ahead(ahead)
+        per = max(1, ahead // spp)
+        warm, updates = 2 * per, max(per, updates // per * per)
+    for _ in range(warm):                               # the ring of scratch regions and the job list for this batch size
         tr.render_accumulate_async(first, spp)
         first += spp
     tr.synchronize()
@@ -149,8 +156,13 @@ def progressive_leg(tr, W, H, first, spp=10, updates=100):
         first += spp
     tr.synchronize()
     dt = time.perf_counter() - t0
-    return {"spp_per_update": spp, "updates": updates, "tonemap_every_update": True, "ms_per_update": dt / updates * 1e3,
-            "value": W * H * spp * updates / dt / 1e6, "unit": "Msamples/s"}, first
+    out = {"spp_per_update": spp, "updates": updates, "tonemap_every_update": True, "ms_per_update": dt / updates * 1e3,
+           "value": W * H * spp * updates / dt / 1e6, "unit": "Msamples/s"}
+    if ahead:
+        out["render_ahead_subframes"] = ahead
+        out["rendered_not_asked_for"] = tr.rendered_subframes() - (first - 1)
+        tr.set_render_ahead(0)
+    return out, first
 
 
 def pmc_traffic(args, S):
@@ -560,6 +572,11 @@ def main():
     if rank == 0 and world == 1 and not args.simple_kernel and not args.no_progressive_leg and not args.sync_steps:
         prog, nxt = progressive_leg(tr, W, H, nxt)
         prog["fraction_of_headline"] = prog["value"] / value
+        # the same calls served by launches of 80 subframes (ct_set_render_ahead): every update still shows the reference's
+        # image for its subframe count, 80 subframes later
+        ahead, nxt = progressive_leg(tr, W, H, nxt, ahead=80)
+        ahead["fraction_of_headline"] = ahead["value"] / value
+        prog["with_render_ahead"] = ahead
         out["progressive_10spp"] = prog
     if rank == 0 and world == 1 and args.estimator == 0 and not args.simple_kernel and not args.no_delta_leg:
         out["delta_estimator"] = delta_leg(ds, tex, W, H, args.mode, S, max(args.steps, 1))

@@ -270,6 +270,16 @@ class CloudTracer:
         (download(CT_BUF_SCREEN) after synchronize())."""
         check(self.L.ct_tonemap_async(self.h, exposure), self.h)
 
+    def set_render_ahead(self, subframes: int):
+        """ct_set_render_ahead: enqueued calls of fewer subframes than this are served by launches of this many, each call
+        accumulating its own share (the reference's 10-subframe display cadence at the speed of long launches)."""
+        check(self.L.ct_set_render_ahead(self.h, subframes), self.h)
+
+    def rendered_subframes(self) -> int:
+        n = C.c_uint32(0)
+        check(self.L.ct_rendered_subframes(self.h, C.byref(n)), self.h)
+        return int(n.value)
+
     def is_converged(self):
         ok, bad = C.c_int32(0), C.c_uint64(0)
         check(self.L.ct_is_converged(self.h, C.byref(ok), C.byref(bad)), self.h)

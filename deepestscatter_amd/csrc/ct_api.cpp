@@ -62,7 +62,9 @@ struct CtHandle_ {
         hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_done = nullptr, ev_acc0 = nullptr, ev_acc1 = nullptr;
         bool pending = false;              // launched, kernel times not booked yet
         bool accumulated = false;          // its accumulate kernel has been enqueued (ev_acc0/1 valid)
-        bool awaits_accumulate = false;    // launched with suspension: A(k) is still to be enqueued
+        bool awaits_accumulate = false;    // in `waiting`: some of its subframes are still to be accumulated
+        bool complete = false;             // no path of the batch is in flight any more (max_age launches have followed, or a flush)
+        uint32_t acc_done = 0;             // subframes of the batch whose accumulate kernels are enqueued
         uint32_t first = 0, S = 0;
         uint32_t rank_base = 0, groups = 0;   // the chunk of pixel groups this launch renders (places in the job order)
         bool with_misses = false;          // its accumulate kernel also accounts for the pixels that miss the box (once per batch)
@@ -70,7 +72,15 @@ struct CtHandle_ {
     Slot slots[kMaxRegions];
     int n_regions = 2;                     // regions of the scratch in use
     int next_slot = 0;
-    std::vector<int> waiting;              // slots whose batch awaits its accumulate kernel, oldest first
+    std::vector<int> waiting;              // slots with subframes still to be accumulated, oldest first
+    // Render-ahead (ct_set_render_ahead, CT_RENDER_AHEAD): enqueued calls of fewer subframes than `ahead` -- the reference's
+    // display loop asks for 10 at a time, Camera.cpp:189 -- are served by estimator launches of `ahead` subframes, of which
+    // every call accumulates its own share: R(k) a(k-M,0) a(k-M,1) .. R(k+1) a(k-M+1,0) ..  A launch of `ahead`
+    // subframes works through a few pixel groups at a time like a long batch does, which a launch of 10 cannot (DESIGN.md
+    // 4.3 item 10).  `rendered` >= `subframes`: the subframes the estimator has been launched for / the caller has asked
+    // for; the running mean follows the calls by M * ahead subframes until something waits (flush: exactly `subframes`).
+    uint32_t ahead = 0;
+    uint32_t rendered = 0;
     uint32_t *cont[2] = { nullptr, nullptr }; // suspended paths: launch k writes cont[k & 1], launch k+1 reads it
     uint64_t launch_no = 0;                // estimator launches enqueued so far
     bool cont_live = false;                // the last launch may have suspended paths: the next one resumes them
@@ -131,6 +141,7 @@ struct CtHandle_ {
     uint32_t *d_queue = nullptr;
     unsigned long long *d_counters = nullptr; // kCounterCount + 1 (unconverged) + kStatCount
     float *d_colsum = nullptr, *d_avg = nullptr;
+    uint32_t reinhard_generation = 0;   // launches on d_avg's barrier counter (launch_reinhard)
 
     // CT_DEBUG_INVARIANTS=1: the diagnostics build of the estimator counts samples dealt / paths resumed / results
     // written / paths suspended, the scratch is filled with NaNs before every launch, and every point at which
@@ -190,6 +201,7 @@ static int fail(CtHandle h, int code, const char *fmt, ...)
 
 static int flush(CtHandle h);
 static int check_invariants(CtHandle h);
+static void discard_ahead(CtHandle h);
 
 #define NEED_NOFLUSH(h)                                \
     do {                                               \
@@ -813,6 +825,9 @@ static int create_impl(const CtScene *s, CtHandle h)
     if (const char *e = getenv("CT_MAX_AGE")) {
         h->max_age_override = std::min(CtHandle_::kMaxRegions - 1, std::max(0, atoi(e)));
     }
+    if (const char *e = getenv("CT_RENDER_AHEAD")) {
+        h->ahead = (uint32_t)std::min(65535, std::max(0, atoi(e)));
+    }
     HIPCHK(h, dmalloc(&h->d_cont_total, 1));
     HIPCHK(h, hipMemsetAsync(h->d_cont_total, 0, sizeof(unsigned long long), h->stream));
     for (auto &c : h->cont) {
@@ -945,6 +960,7 @@ extern "C" int ct_set_camera(CtHandle h, const float eye[3], const float U[3], c
     d.wx = W[0]; d.wy = W[1]; d.wz = W[2];
     h->camera_set = true;
     h->queue_dirty = true; // primary rays and the work queue depend on the pose
+    discard_ahead(h);      // (and so does every sample rendered ahead of the calls)
     return CT_OK;
 }
 
@@ -1345,6 +1361,7 @@ static int ensure_frames(CtHandle h, uint32_t S, bool relayout)
     if (!relayout && need <= h->slot_capacity) {
         return CT_OK;   // (a waited-for batch, the cost-measuring launch: any region that is large enough will do)
     }
+    discard_ahead(h);
     const uint64_t budget = 2 * scratch_slot_bytes(h) / sizeof(float4);
     // (a waited-for batch needs one region; the others are allocated when batches are first enqueued)
     const int regions = relayout ? wanted_regions(h, S, need, std::max<uint64_t>(budget, 2 * need)) : 1;
@@ -1398,23 +1415,74 @@ static int collect(CtHandle h, CtHandle_::Slot &sl)
     return CT_OK;
 }
 
-static int enqueue_accumulate(CtHandle h, CtHandle_::Slot &sl, const float4 *frames, bool dense)
+// The accumulate kernel(s) for subframes [sl.acc_done, sl.acc_done + n) of a slot's batch.
+static int enqueue_accumulate(CtHandle h, CtHandle_::Slot &sl, const float4 *frames, bool dense, uint32_t n)
 {
     const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
+    const uint32_t off = sl.acc_done;
     HIPCHK(h, hipEventRecord(sl.ev_acc0, h->stream));
     if (simple || dense) {
-        HIPCHK(h, launch_accumulate_batch(frames, h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width, h->scene.height,
-                                          h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
+        HIPCHK(h, launch_accumulate_batch(frames + (size_t)off * h->scene.width * h->scene.height, h->d_mean, h->d_m2, sl.first + off, n,
+                                          h->scene.width, h->scene.height, h->scene.shard_index, h->scene.shard_count,
+                                          h->d_counters + 8, h->stream));
     } else {
-        HIPCHK(h, launch_accumulate_list(frames, (uint32_t)frame_stride(h), h->d_pixels, sl.groups * 64u,
+        HIPCHK(h, launch_accumulate_list(frames + (size_t)off * frame_stride(h), (uint32_t)frame_stride(h), h->d_pixels, sl.groups * 64u,
                                          h->n_chunks <= 1 ? nullptr : h->d_group_order, sl.rank_base,
-                                         sl.with_misses, h->d_primary, h->d_mean, h->d_m2, sl.first, sl.S, h->scene.width,
+                                         sl.with_misses, h->d_primary, h->d_mean, h->d_m2, sl.first + off, n, h->scene.width,
                                          h->scene.height, h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
     }
-    HIPCHK(h, hipEventRecord(sl.ev_acc1, h->stream));
+    HIPCHK(h, hipEventRecord(sl.ev_acc1, h->stream));   // (of several partial accumulates the last one is the one whose time is booked)
     sl.accumulated = true;
-    sl.awaits_accumulate = false;
+    sl.acc_done += n;
     return CT_OK;
+}
+
+// How far the running mean may follow: everything that is complete, or -- with render-ahead -- the calls minus the lag that
+// lets every call find its share complete (see CtHandle_::ahead).
+static uint32_t accumulate_target(CtHandle h)
+{
+    if (h->ahead == 0) {
+        return 0xffffffffu;
+    }
+    const uint64_t lag = (uint64_t)std::max(h->n_regions - 1, 1) * h->ahead;
+    return h->subframes > lag ? (uint32_t)(h->subframes - lag) : 0u;
+}
+
+// Enqueues the accumulate kernels of the complete batches, oldest first, up to subframe `target`.
+static int advance_accumulate(CtHandle h, uint32_t target)
+{
+    while (!h->waiting.empty()) {
+        const int w = h->waiting.front();
+        CtHandle_::Slot &sl = h->slots[w];
+        if (!sl.complete) {
+            break;
+        }
+        const uint32_t next = sl.first + sl.acc_done, last = sl.first + sl.S - 1u;
+        const uint32_t upto = std::min(last, target);
+        if (upto >= next && sl.acc_done < sl.S) {
+            const int rc = enqueue_accumulate(h, sl, slot_frames(h, w), false, upto - next + 1u);
+            if (rc != CT_OK) {
+                return rc;
+            }
+        }
+        if (sl.acc_done < sl.S) {
+            break;
+        }
+        sl.awaits_accumulate = false;
+        h->waiting.erase(h->waiting.begin());
+    }
+    return CT_OK;
+}
+
+// Forgets the subframes that were rendered ahead of the calls (the pose, the layout of the scratch or the count of
+// subframes changes).  Nothing may be in flight: the caller has flushed, so what is left in `waiting` is exactly that.
+static void discard_ahead(CtHandle h)
+{
+    for (int w : h->waiting) {
+        h->slots[w].awaits_accumulate = false;
+    }
+    h->waiting.clear();
+    h->rendered = h->subframes;
 }
 
 // The estimator launch itself: the kernel that fits the handle and the batch.
@@ -1551,21 +1619,24 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     sl.pending = true;
     sl.accumulated = false;
     sl.awaits_accumulate = false;
+    sl.complete = false;
+    sl.acc_done = 0;
     if (accumulate) {
         if (suspend) {
             sl.awaits_accumulate = true;
             h->waiting.push_back(slot);
-            // every batch that max_age launches have followed is complete: its accumulate kernel goes behind this launch
-            while (h->waiting.size() > (size_t)max_age) {
-                const int w = h->waiting.front();
-                h->waiting.erase(h->waiting.begin());
-                const int rc = enqueue_accumulate(h, h->slots[w], slot_frames(h, w), false);
-                if (rc != CT_OK) {
-                    return rc;
+            // every batch that max_age launches have followed is complete: its accumulate kernels may go behind this launch
+            uint32_t younger = 0;
+            for (size_t i = h->waiting.size(); i-- > 0;) {
+                CtHandle_::Slot &w = h->slots[h->waiting[i]];
+                if (!w.complete && ++younger > max_age) {
+                    w.complete = true;
                 }
             }
+            return advance_accumulate(h, accumulate_target(h));
         } else {
-            const int rc = enqueue_accumulate(h, sl, dense ? dense_frames : slot_frames(h, slot), dense);
+            sl.complete = true;
+            const int rc = enqueue_accumulate(h, sl, dense ? dense_frames : slot_frames(h, slot), dense, S);
             if (rc != CT_OK) {
                 return rc;
             }
@@ -1643,12 +1714,15 @@ static int flush(CtHandle h)
         }
     }
     for (int w : h->waiting) {
-        const int rc = enqueue_accumulate(h, h->slots[w], slot_frames(h, w), false);
+        h->slots[w].complete = true;
+    }
+    {
+        // everything the caller has asked for; what was rendered ahead of the calls stays in its region for the next ones
+        const int rc = advance_accumulate(h, h->ahead ? h->subframes : 0xffffffffu);
         if (rc != CT_OK) {
             return rc;
         }
     }
-    h->waiting.clear();
     for (int k = 0; k < CtHandle_::kMaxRegions; k++) {
         const int rc = collect(h, h->slots[k]);
         if (rc != CT_OK) {
@@ -1669,6 +1743,7 @@ static int prepare_batches(CtHandle h, uint32_t S)
     }
     if (h->queue_dirty) {
         int rc = flush(h);
+        discard_ahead(h);
         if (rc == CT_OK) {
             rc = rebuild_queue(h);
         }
@@ -1679,6 +1754,7 @@ static int prepare_batches(CtHandle h, uint32_t S)
     const uint32_t want = groups_per_chunk(h, S);
     if (h->jobs_S < S || h->jobs_brief != short_batch(h, S) || h->chunk_groups != want || h->chunk_q_begin.empty()) {
         const int rc = flush(h);   // the job list (and with it the layout of the scratch) changes: nothing may be in flight
+        discard_ahead(h);
         return rc == CT_OK ? build_jobs(h, S, want) : rc;
     }
     return CT_OK;
@@ -1689,6 +1765,7 @@ static int prepare_batches(CtHandle h, uint32_t S)
 static int run_batch(CtHandle h, float4 *dense_frames, uint32_t first, uint32_t S, bool accumulate)
 {
     int rc = flush(h);
+    discard_ahead(h);   // (slot 0 is about to be reused)
     if (rc == CT_OK) {
         rc = prepare_batches(h, S);
     }
@@ -1752,6 +1829,7 @@ extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *fram
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
     h->accum_ms += ms;
     h->subframes = subframe_id;
+    discard_ahead(h);
     return CT_OK;
 }
 
@@ -1771,6 +1849,23 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
         return wait ? flush(h) : CT_OK;
     }
     const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
+    if (h->rendered > h->subframes) {
+        // some of these subframes were rendered ahead of the calls: their samples wait in the scratch
+        const uint32_t covered = std::min(count, h->rendered - h->subframes);
+        h->subframes += covered;
+        first_subframe_id += covered;
+        count -= covered;
+        if (count == 0) {
+            const int rc = advance_accumulate(h, accumulate_target(h));
+            return rc != CT_OK ? rc : (wait ? flush(h) : CT_OK);
+        }
+    }
+    // (from here on every rendered subframe has been asked for)
+    const uint32_t asked_end = h->subframes + count;
+    if (!wait && h->ahead > count && !simple && h->continuation && h->order_tuned && !h->queue_dirty &&
+        groups_per_chunk(h, h->ahead) >= h->n_groups) {
+        count = h->ahead;   // the launch renders ahead of the calls; this call accumulates its own share
+    }
     if (h->queue_dirty && !simple) {
         int rc = flush(h);
         if (rc == CT_OK) {
@@ -1847,7 +1942,16 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             }
             for (uint32_t c = 0; c < std::max(h->n_chunks, 1u) && rc == CT_OK; c++) {
                 const int slot = h->next_slot;
-                rc = collect(h, h->slots[slot]); // book the launch that used this region n_regions launches ago
+                if (rc == CT_OK && h->slots[slot].awaits_accumulate) {
+                    // the region's previous batch: with render-ahead its last share is due now at the latest
+                    h->subframes = std::min(h->rendered + S, asked_end);
+                    rc = advance_accumulate(h, accumulate_target(h));
+                    h->subframes = std::min(h->rendered, asked_end);
+                    if (rc == CT_OK && h->slots[slot].awaits_accumulate) {
+                        rc = fail(h, CT_E_STATE, "internal: scratch region %d is reused before its batch is accumulated", slot);
+                    }
+                }
+                rc = rc == CT_OK ? collect(h, h->slots[slot]) : rc; // book the launch that used this region n_regions launches ago
                 const auto t2 = std::chrono::steady_clock::now();
                 if (rc == CT_OK) {
                     const bool suspend = enqueue && h->continuation && !simple;
@@ -1871,7 +1975,15 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             return rc;
         }
         done += S;
-        h->subframes += S;
+        h->rendered += S;
+        h->subframes = std::min(h->rendered, asked_end);
+        if (h->ahead && rc == CT_OK) {
+            rc = advance_accumulate(h, accumulate_target(h));   // (the launch was enqueued before the count moved)
+            if (rc != CT_OK) {
+                flush(h);
+                return rc;
+            }
+        }
     }
     return wait ? flush(h) : CT_OK;
 }
@@ -1886,6 +1998,26 @@ extern "C" int ct_render_accumulate_async(CtHandle h, uint32_t first_subframe_id
 {
     NEED_NOFLUSH(h);
     return render_accumulate_impl(h, first_subframe_id, count, false);
+}
+
+extern "C" int ct_set_render_ahead(CtHandle h, uint32_t subframes)
+{
+    NEED(h);
+    if (subframes > 0xffffu) {
+        return fail(h, CT_E_INVAL, "render-ahead of %u subframes (a launch holds at most 65535)", subframes);
+    }
+    discard_ahead(h);
+    h->ahead = subframes;
+    return CT_OK;
+}
+
+extern "C" int ct_rendered_subframes(CtHandle h, uint32_t *count_out)
+{
+    NEED_NOFLUSH(h);
+    if (count_out) {
+        *count_out = std::max(h->rendered, h->subframes);
+    }
+    return CT_OK;
 }
 
 extern "C" int ct_synchronize(CtHandle h)
@@ -2150,6 +2282,7 @@ extern "C" int ct_reset(CtHandle h)
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1 + kStatCount) * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->subframes = 0;
+    discard_ahead(h);
     h->render_ms = h->accum_ms = 0;
     h->launches = 0;
     h->host_paths = h->host_hits = 0;
@@ -2160,7 +2293,7 @@ extern "C" int ct_reset(CtHandle h)
 static int tonemap_impl(CtHandle h, const float4 *mean, float exposure, uint8_t *rgba_host, float *avg_luminance_out)
 {
     HIPCHK(h, launch_reinhard(mean, h->scene.width, h->scene.height, exposure, h->d_colsum, h->d_avg,
-                              h->d_screen, h->stream));
+                              h->d_screen, &h->reinhard_generation, h->stream));
     if (rgba_host) {
         HIPCHK(h, hipMemcpyAsync(rgba_host, h->d_screen, (size_t)h->scene.width * h->scene.height * sizeof(uchar4),
                                  hipMemcpyDeviceToHost, h->stream));
@@ -2182,7 +2315,8 @@ extern "C" int ct_tonemap_async(CtHandle h, float exposure)
 {
     NEED_NOFLUSH(h);
     // (behind whatever is enqueued: the running mean of the batches whose accumulate kernels precede it on the stream)
-    HIPCHK(h, launch_reinhard(h->d_mean, h->scene.width, h->scene.height, exposure, h->d_colsum, h->d_avg, h->d_screen, h->stream));
+    HIPCHK(h, launch_reinhard(h->d_mean, h->scene.width, h->scene.height, exposure, h->d_colsum, h->d_avg, h->d_screen, &h->reinhard_generation,
+                              h->stream));
     return CT_OK;
 }
 
@@ -2339,6 +2473,7 @@ extern "C" int ct_set_subframes(CtHandle h, uint32_t count)
 {
     NEED(h);
     h->subframes = count;
+    discard_ahead(h);
     return CT_OK;
 }
 

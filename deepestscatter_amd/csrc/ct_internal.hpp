@@ -151,7 +151,7 @@ hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, c
                                   uint32_t shard_index, uint32_t shard_count, unsigned long long *bad_samples,
                                   hipStream_t stream);
 hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure,
-                           float *column_sums, float *avg, uchar4 *screen, hipStream_t stream);
+                           float *column_sums, float *avg, uchar4 *screen, uint32_t *generation, hipStream_t stream);
 hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,
                             unsigned long long *unconverged, hipStream_t stream);
 hipError_t launch_cdf_selftest(const float *cdf, const uint16_t *guide, uint32_t first_u24, uint32_t count,

@@ -2569,13 +2569,17 @@ CT_DEV float luminance4(float4 c)
 }
 
 // One launch for firstPass + secondPass + applyReinhard (the reference launches three, Camera.cpp:202-210; BASELINE.json
-// asks for a fused epilogue).  Phase 1: one thread per column sums it from y = 0 upwards.  Grid barrier (the grid has at most
+// asks for a fused epilogue).  Phase 1: the column sums, every column from y = 0 upwards.  Grid barrier (the grid has at most
 // one block per CU, so every block is resident or will be without anyone's help).  Phase 2: EVERY block adds the W
 // column sums itself, in column order, in one lane -- the same float additions as secondPass's single thread, so no
 // second barrier and no broadcast are needed.  Phase 3: applyReinhard over the pixels, grid-stride.
-__global__ __launch_bounds__(256) void reinhard_fused_kernel(const float4 *__restrict__ mean, uint32_t width, uint32_t height,
-                                                             float exposure, float *column_sums, float *__restrict__ avg_out,
-                                                             uint32_t *barrier, uchar4 *__restrict__ screen)
+// The barrier counts up for ever: launch n waits for n * gridDim.x arrivals (`barrier_target`), so no launch has to zero it.
+constexpr uint32_t kReinhardThreads = 1024, kReinhardCols = 4;
+
+__global__ __launch_bounds__(kReinhardThreads) void reinhard_fused_kernel(const float4 *__restrict__ mean, uint32_t width, uint32_t height,
+                                                                          float exposure, float *column_sums, float *__restrict__ avg_out,
+                                                                          uint32_t *barrier, uint32_t barrier_target,
+                                                                          uchar4 *__restrict__ screen)
 {
     extern __shared__ float cols[]; // width floats
     __shared__ float avg_s;
@@ -2583,54 +2587,58 @@ __global__ __launch_bounds__(256) void reinhard_fused_kernel(const float4 *__res
     const float DELTA = 0.00001f;
     // firstPass, reinhard.cu:29-40: per column, sum += luminance + DELTA for y = 0 .. height-1 -- IN THAT ORDER (float adds do
     // not commute with regrouping, and the tonemapped bytes must equal the reference's arithmetic).  A thread per column that
-    // loads as it adds is a chain of `height` dependent memory round trips (1.9 ms at 1024^2: more than a 10-subframe
-    // update's accumulate and half of its estimator launch).  So the loads are taken out of the chain: a block takes 32
-    // columns, its 256 threads fetch 64 rows of them at once and leave luminance + DELTA in LDS, and 32 threads add the 64
-    // values of their column in order; only the adds are serial.
+    // loads as it adds is a chain of `height` dependent memory round trips (1.9 ms at 1024^2).  So the loads are taken out of
+    // the chain, and spread over the whole chip: a block takes FOUR columns (64 B of every row), its 1024 threads fetch 1024
+    // rows of them at once and leave luminance + DELTA in LDS, and one lane per column -- in four different waves -- adds the
+    // values in order; only the adds are serial (~3 us per 1024 rows).  (Round 3 until here: 32 columns per block, 64 rows at a
+    // time -- 32 busy blocks and 16 dependent round trips at 1024^2, 0.12 ms of a 0.23 ms kernel that a 10-subframe display
+    // update pays every time.)
     {
-        __shared__ float tile[64][33];
-        const uint32_t groups = (width + 31u) / 32u;
-        const uint32_t cx = threadIdx.x & 31u, ry = threadIdx.x >> 5;   // 32 columns x 8 rows per pass
+        __shared__ float lum[kReinhardCols][kReinhardThreads];
+        const uint32_t groups = (width + kReinhardCols - 1u) / kReinhardCols;
+        const uint32_t adder = threadIdx.x >> 6;   // lane 0 of waves 0..3 adds column `adder` of the group
+        const bool adds = (threadIdx.x & 63u) == 0u && adder < kReinhardCols;
         for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
-            const uint32_t x = g * 32u + cx;
+            const uint32_t x0 = g * kReinhardCols;
             float sum = 0;
-            for (uint32_t y0 = 0; y0 < height; y0 += 64u) {
-                float v[8];
+            for (uint32_t y0 = 0; y0 < height; y0 += kReinhardThreads) {
+                const uint32_t y = y0 + threadIdx.x;
+                float v[kReinhardCols];
 #pragma unroll
-                for (uint32_t k = 0; k < 8u; k++) {
-                    const uint32_t y = y0 + ry + 8u * k;
-                    v[k] = (x < width && y < height) ? luminance4(mean[(size_t)y * width + x]) + DELTA : 0.f;
+                for (uint32_t c = 0; c < kReinhardCols; c++) {
+                    v[c] = (x0 + c < width && y < height) ? luminance4(mean[(size_t)y * width + x0 + c]) + DELTA : 0.f;
                 }
-                __syncthreads();   // (the previous tile has been added up)
+                __syncthreads();   // (the previous rows have been added up)
 #pragma unroll
-                for (uint32_t k = 0; k < 8u; k++) {
-                    tile[ry + 8u * k][cx] = v[k];
+                for (uint32_t c = 0; c < kReinhardCols; c++) {
+                    lum[c][threadIdx.x] = v[c];
                 }
                 __syncthreads();
-                if (threadIdx.x < 32u && x < width) {
-                    const uint32_t rows = min(64u, height - y0);
-                    if (rows == 64u) {
-#pragma unroll
-                        for (uint32_t r = 0; r < 64u; r++) {
-                            sum += tile[r][cx];
+                if (adds) {
+                    const uint32_t rows = min(kReinhardThreads, height - y0);
+                    if (rows == kReinhardThreads) {
+#pragma unroll 16
+                        for (uint32_t r = 0; r < kReinhardThreads; r++) {
+                            sum += lum[adder][r];
                         }
                     } else {
                         for (uint32_t r = 0; r < rows; r++) {
-                            sum += tile[r][cx];
+                            sum += lum[adder][r];
                         }
                     }
                 }
             }
-            if (threadIdx.x < 32u && x < width) {
-                __hip_atomic_store(column_sums + x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (adds && x0 + adder < width) {
+                __hip_atomic_store(column_sums + x0 + adder, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(barrier, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            __builtin_amdgcn_s_sleep(4);
+        // (wrap-safe: the host starts the count again long before 2^31)
+        while ((int32_t)(__hip_atomic_load(barrier, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - barrier_target) < 0) {
+            __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();
@@ -2669,25 +2677,32 @@ __global__ __launch_bounds__(256) void reinhard_fused_kernel(const float4 *__res
     }
 }
 
-// `avg` points at two words: the average luminance and the grid barrier's counter.
+// `avg` points at two words: the average luminance and the grid barrier's counter.  `generation` (host, one per `avg`)
+// counts the launches on that counter; 0 = the counter is to be zeroed first.
 hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure, float *column_sums,
-                           float *avg, uchar4 *screen, hipStream_t stream)
+                           float *avg, uchar4 *screen, uint32_t *generation, hipStream_t stream)
 {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
         cus = 64;
     }
     const uint32_t pixels = width * height;
-    const uint32_t blocks = std::min<uint32_t>((uint32_t)cus, (pixels + 255u) / 256u);
+    const uint32_t blocks = std::min<uint32_t>((uint32_t)cus, (pixels + kReinhardThreads - 1u) / kReinhardThreads);
     if ((size_t)width * sizeof(float) > 48u * 1024u) {
         return hipErrorInvalidValue;   // (the column sums of a row do not fit the kernel's LDS: frames up to 12288 pixels wide)
     }
-    hipError_t e = hipMemsetAsync(avg + 1, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) {
-        return e;
+    uint32_t local_generation = 0;
+    uint32_t &gen = generation ? *generation : local_generation;
+    if (gen == 0 || (uint64_t)(gen + 1u) * blocks >= 0x40000000ull) {
+        const hipError_t e = hipMemsetAsync(avg + 1, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) {
+            return e;
+        }
+        gen = 0;
     }
-    hipLaunchKernelGGL(reinhard_fused_kernel, dim3(blocks), dim3(256), width * sizeof(float), stream, mean, width, height, exposure,
-                       column_sums, avg, (uint32_t *)(avg + 1), screen);
+    gen += 1;
+    hipLaunchKernelGGL(reinhard_fused_kernel, dim3(blocks), dim3(kReinhardThreads), width * sizeof(float), stream, mean, width, height,
+                       exposure, column_sums, avg, (uint32_t *)(avg + 1), gen * blocks, screen);
     return hipGetLastError();
 }
 

@@ -211,6 +211,20 @@ CT_API int ct_render_accumulate(CtHandle h, uint32_t first_subframe_id, uint32_t
 CT_API int ct_render_accumulate_async(CtHandle h, uint32_t first_subframe_id, uint32_t count);
 CT_API int ct_synchronize(CtHandle h);
 
+/* Render-ahead for the reference's display cadence (Camera::render: 10 subframes, then tonemap and display,
+ * Camera.cpp:189-214).  With subframes > 0, a call of ct_render_accumulate_async for FEWER subframes than that is served by
+ * an estimator launch of `subframes` subframes -- which works through a few pixel groups at a time, as a long batch does,
+ * where a launch of 10 subframes has every group of the image in flight at once and misses L2 58 % more often (DESIGN.md
+ * 4.3 items 10, 13) -- and every call accumulates ITS OWN share of it, in order: the images the calls produce are the
+ * reference's images for those subframe counts, bit for bit, each a fixed number of calls later (the running mean follows
+ * the calls by `subframes` subframes per launch a path may span; ct_synchronize and every entry point that waits bring it
+ * to exactly the subframes asked for).  Samples rendered ahead and not asked for yet stay in the scratch for the next
+ * calls; ct_set_camera, ct_reset, ct_set_subframes and ct_accumulate drop them, and CtCounters count them when they are
+ * rendered.  0 (the default) turns it off; also CT_RENDER_AHEAD in the environment at ct_create.
+ * ct_rendered_subframes: how far the estimator has been launched (>= ct_subframes). */
+CT_API int ct_set_render_ahead(CtHandle h, uint32_t subframes);
+CT_API int ct_rendered_subframes(CtHandle h, uint32_t *count_out);
+
 /* Camera::reset, Camera.cpp:77-86 (clearScreen, progressive.cu:29-34): zero frame, mean, M2,
  * subframe count.  Counters are zeroed too. */
 CT_API int ct_reset(CtHandle h);

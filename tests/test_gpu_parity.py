@@ -1303,6 +1303,68 @@ def test_short_batches_with_repeated_suspension_are_bit_exact(estimator, max_age
 
 
 @pytest.mark.parametrize("estimator", [0, 1])
+@pytest.mark.parametrize("max_age", ["0", "3"])
+def test_render_ahead_serves_the_display_cadence_bit_exactly(estimator, max_age, monkeypatch):
+    """ct_set_render_ahead: enqueued calls of 10 subframes (Camera.cpp:189) are served by launches of 40, every call
+    accumulating its own share.  Whenever something waits, the running mean is the one of exactly the subframes asked for --
+    the waited-for handle's frame at that count, bit for bit -- although the estimator has run ahead; waited-for calls use up
+    what was rendered ahead; a new pose drops it.  Invariants armed (every sample written exactly once)."""
+    tex = ds.make_procedural_cloud(96)
+    w = h = 160
+    ref = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+    want, first = {}, 1
+    for upto in (30, 70, 130, 160):
+        ref.render_accumulate(first, upto - first + 1)
+        want[upto] = (ref.mean(), ref.m2(), ref.counters(), ref.tonemap(0.4)[0])
+        first = upto + 1
+    eye = (0.3, 2.2, 0.9)
+    U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
+    ref.set_camera(eye, U, V, W)
+    ref.reset()
+    ref.render_accumulate(1, 20)
+    want["pose2"] = (ref.mean(), ref.m2())
+    ref.close()
+
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    monkeypatch.setenv("CT_MAX_AGE", max_age)
+    tr = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+    tr.set_render_ahead(40)
+
+    def updates(first, n):
+        for k in range(n):
+            tr.render_accumulate_async(first + 10 * k, 10)
+            tr.tonemap_async(0.4)
+
+    def same(upto):
+        return np.array_equal(tr.mean(), want[upto][0]) and np.array_equal(tr.m2(), want[upto][1])
+
+    updates(1, 3)                     # the cost-measuring launch of 10, then a launch of 40: subframes 11..50
+    tr.synchronize()
+    assert tr.rendered_subframes() == 50 and same(30)
+    updates(31, 4)                    # 31..50 are there; 51..90 are launched by the third of these calls
+    assert same(70) and tr.rendered_subframes() == 90
+    tr.tonemap_async(0.4)
+    tr.synchronize()
+    assert np.array_equal(np.asarray(tr.download(_lib.CT_BUF_SCREEN)).reshape(h, w, 4), want[70][3])
+    tr.render_accumulate(71, 60)      # a waited-for call: 20 subframes from the scratch, 40 rendered now
+    assert same(130) and tr.rendered_subframes() == 130
+    assert tr.counters() == want[130][2]            # (nothing rendered that was not asked for)
+    updates(131, 3)
+    assert same(160) and tr.rendered_subframes() == 170
+    assert tr.counters()["paths"] == want[160][2]["paths"] // 160 * 170
+    iv = tr.debug_invariants()
+    assert iv["armed"] == 1 and iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+    assert iv["resumed"] == iv["suspended"] > 0, iv
+    tr.set_camera(eye, U, V, W)      # the ten subframes rendered ahead are of the old pose
+    tr.reset()
+    updates(1, 2)
+    assert np.array_equal(tr.mean(), want["pose2"][0]) and np.array_equal(tr.m2(), want["pose2"][1])
+    iv = tr.debug_invariants()
+    tr.close()
+    assert iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
 def test_batches_cut_by_pixel_groups_are_bit_exact(estimator, monkeypatch):
     """A batch whose samples do not fit one scratch region is rendered chunk by chunk of PIXEL GROUPS -- every launch all the
     subframes of a piece of the cost-sorted group order, its results in columns of its own, accumulated by its own kernel --

@@ -12,13 +12,20 @@ sys.path.insert(0, str(ROOT))
 import numpy as np
 
 
-def run(a, spp, updates, tonemap=True):
+def run(a, spp, updates, tonemap=True, ahead=0):
     import deepestscatter_amd as ds
     tex = run.tex
     tr = ds.CloudTracer(tex, width=a.size, height=a.size, estimator=a.estimator)
     tr.render_accumulate(1, 32)                       # cost-measuring launch of the pose
     first = 33
-    for _ in range(max(4, 64 // spp)):                # warm-up: scratch ring, job list for this batch size
+    warm = max(4, 64 // spp)
+    if ahead:
+        # (whole launches in the warm-up and in the timed region: what is timed is what is counted)
+        tr.set_render_ahead(ahead)
+        per = max(1, ahead // spp)
+        warm = 2 * per
+        updates = max(per, updates // per * per)
+    for _ in range(warm):                             # warm-up: scratch ring, job list for this batch size
         tr.render_accumulate_async(first, spp); first += spp
     tr.synchronize()
     t0 = time.perf_counter()
@@ -30,7 +37,8 @@ def run(a, spp, updates, tonemap=True):
     dt = time.perf_counter() - t0
     out = {"spp_per_update": spp, "updates": updates, "tonemap_every_update": tonemap, "ms_per_update": dt / updates * 1e3,
            "Msamples_per_s": a.size * a.size * spp * updates / dt / 1e6, "suspended_paths": tr.debug_suspended(),
-           "checksum": float(tr.mean().astype(np.float64).sum())}
+           "checksum": float(tr.mean().astype(np.float64).sum()), "render_ahead": ahead,
+           "asked_subframes": first - 1, "rendered_subframes": tr.rendered_subframes()}
     tr.close()
     return out
 
@@ -42,6 +50,7 @@ if __name__ == "__main__":
     ap.add_argument("--estimator", type=int, default=0)
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--ahead", type=int, nargs="*", default=[], help="also with ct_set_render_ahead(N) for every N given")
     ap.add_argument("--reference-spp", type=int, default=1000, help="the long batch the rate is compared with (0 = skip)")
     a = ap.parse_args()
     import deepestscatter_amd as ds
@@ -51,6 +60,11 @@ if __name__ == "__main__":
         r = run(a, spp, max(2, a.updates * 10 // spp) if spp != 10 else a.updates)
         print(json.dumps(r), flush=True)
         res["runs"].append(r)
+        for ahead in a.ahead:
+            if ahead > spp:
+                r = run(a, spp, a.updates, ahead=ahead)
+                print(json.dumps(r), flush=True)
+                res["runs"].append(r)
     if a.reference_spp:
         r = run(a, a.reference_spp, 2, tonemap=False)
         print("reference", json.dumps(r), flush=True)

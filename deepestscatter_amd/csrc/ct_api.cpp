@@ -1548,6 +1548,7 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         ba.reverse = (uint32_t)(h->launch_no & 1u);
     }
     const int buf_out = (int)(h->launch_no & 1u), buf_in = buf_out ^ 1;
+    ZeroList zero;
     if (h->cont_live) {
         ba.cont_in = h->cont[buf_in];
         ba.cont_in_count = h->d_cont_count + buf_in;
@@ -1555,8 +1556,8 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
         ba.left_in = h->left[buf_in];
         ba.left_in_count = h->d_cont_count + 3 + buf_in;
         ba.left_cursor = h->d_cont_count + 5;
-        HIPCHK(h, hipMemsetAsync(h->d_cont_count + 2, 0, sizeof(uint32_t), h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_cont_count + 5, 0, sizeof(uint32_t), h->stream));
+        zero.add(h->d_cont_count + 2, 1);
+        zero.add(h->d_cont_count + 5, 1);
     }
     if (suspend) {
         ba.cont_out = h->cont[buf_out];
@@ -1569,10 +1570,11 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
             ba.left_out_count = h->d_cont_count + 3 + buf_out;
             ba.left_capacity = (uint32_t)h->left_capacity;
         }
-        HIPCHK(h, hipMemsetAsync(h->d_cont_count + buf_out, 0, sizeof(uint32_t), h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_cont_count + 3 + buf_out, 0, sizeof(uint32_t), h->stream));
+        zero.add(h->d_cont_count + buf_out, 1);
+        zero.add(h->d_cont_count + 3 + buf_out, 1);
     }
-    HIPCHK(h, hipMemsetAsync(sl.queue, 0, kQueueWords * sizeof(uint32_t), h->stream));
+    zero.add(sl.queue, kQueueWords);
+    HIPCHK(h, launch_zero_words(zero, h->stream));
     if (h->debug_invariants && !simple && !dense && h->n_groups != 0) {
         // NaNs (with a NaN alpha) wherever this batch is going to write: a sample that is never written cannot
         // pass for the one an earlier batch left there

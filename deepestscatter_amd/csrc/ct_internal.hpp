@@ -136,6 +136,15 @@ hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, uint32_t zero_face
 hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream);
 hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);
 hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);
+// Zeroes up to six short word arrays in ONE dispatch (the counters a launch of the estimator starts from: five memsets
+// of a few words each were five dispatches of 5 us in front of every 10-subframe launch).
+struct ZeroList {
+    uint32_t *ptr[6];
+    uint32_t words[6];
+    int n = 0;
+    void add(uint32_t *p, uint32_t w) { ptr[n] = p; words[n] = w; n += 1; }
+};
+hipError_t launch_zero_words(const ZeroList &z, hipStream_t stream);
 hipError_t launch_fill_frame(float4 *frame, uint32_t width, uint32_t height, uint32_t shard_index,
                              uint32_t shard_count, hipStream_t stream);
 hipError_t launch_render_persistent(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);

@@ -11,7 +11,7 @@
 //   primary_rays_kernel, primary_advance_kernel, primary_advance_delta_kernel
 //                              per pose: primary ray per pixel and the part of its flight that is the same
 //                              for every sample of the pixel
-//   accumulate_batch_kernel, accumulate_list_kernel, accumulate_miss_kernel
+//   accumulate_batch_kernel, accumulate_list_kernel
 //                              updateFrameResult (progressive.cu:17-27) over S subframes in order
 //   inscatter_kernel           inScatter.cu:40-66
 //   build_bricks_kernel, brick_free_kernel, brick_dist_relax_kernel, brick_meta_kernel
@@ -566,6 +566,23 @@ __global__ void fill_frame_kernel(float4 *__restrict__ frame, uint32_t width, ui
     }
     const bool own = tile_owner(x / kTile, y / kTile, shard_count) == shard_index;
     frame[(size_t)y * width + x] = make_float4(0.f, 0.f, 0.f, own ? 1.f : 0.f);
+}
+
+__global__ __launch_bounds__(64) void zero_words_kernel(ZeroList z)
+{
+    for (int k = 0; k < z.n; k++) {
+        for (uint32_t i = threadIdx.x; i < z.words[k]; i += 64u) {
+            z.ptr[k][i] = 0u;
+        }
+    }
+}
+
+hipError_t launch_zero_words(const ZeroList &z, hipStream_t stream)
+{
+    if (z.n > 0) {
+        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, stream, z);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_fill_frame(float4 *frame, uint32_t width, uint32_t height, uint32_t shard_index,
@@ -2463,14 +2480,42 @@ hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m
     return hipGetLastError();
 }
 
-// Compact form, part 1: one thread per entry of the pixel list (this shard's box-hitting pixels).
+// Compact form: one thread per entry of the pixel list (this shard's box-hitting pixels) in the first `list_blocks`
+// blocks; behind them (with_misses) one thread per pixel of the frame for this shard's pixels whose primary ray misses the
+// box: those are never rendered, their sample is (0,0,0,1) every subframe (empty miss program, progressive.cu:44-46).  One
+// dispatch for both: a display update of 10 subframes pays every dispatch it makes.
 __global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__restrict__ frames, uint32_t frame_stride,
                                                               const uint32_t *__restrict__ pixels, uint32_t n_entries,
                                                               const uint32_t *__restrict__ group_order, uint32_t rank_base,
                                                               float4 *__restrict__ mean, float4 *__restrict__ m2,
                                                               uint32_t first_subframe, uint32_t S,
-                                                              unsigned long long *__restrict__ bad_samples)
+                                                              unsigned long long *__restrict__ bad_samples,
+                                                              uint32_t list_blocks, const float4 *__restrict__ primary,
+                                                              uint32_t width, uint32_t height, uint32_t shard_index,
+                                                              uint32_t shard_count)
 {
+    if (blockIdx.x >= list_blocks) {
+        const uint32_t m = blockIdx.x - list_blocks, gx = (width + 31u) / 32u;
+        const uint32_t x = (m % gx) * 32u + (threadIdx.x & 31u);
+        const uint32_t y = (m / gx) * 8u + (threadIdx.x >> 5);
+        if (x >= width || y >= height) {
+            return;
+        }
+        if (tile_owner(x / kTile, y / kTile, shard_count) != shard_index) {
+            return;
+        }
+        const size_t pix = (size_t)y * width + x;
+        if (primary[2 * pix].w != 0.f) {
+            return;
+        }
+        float4 mu = mean[pix], var = m2[pix];
+        for (uint32_t s = 0; s < S; s++) {
+            welford(mu, var, make_float4(0.f, 0.f, 0.f, 1.f), first_subframe + s);
+        }
+        mean[pix] = mu;
+        m2[pix] = var;
+        return;
+    }
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries) {
         return;
@@ -2511,34 +2556,6 @@ __global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__re
     }
 }
 
-// Compact form, part 2: this shard's pixels whose primary ray misses the box are never rendered;
-// their sample is (0,0,0,1) every subframe (empty miss program, progressive.cu:44-46).
-__global__ __launch_bounds__(256) void accumulate_miss_kernel(const float4 *__restrict__ primary,
-                                                              float4 *__restrict__ mean, float4 *__restrict__ m2,
-                                                              uint32_t first_subframe, uint32_t S, uint32_t width,
-                                                              uint32_t height, uint32_t shard_index,
-                                                              uint32_t shard_count)
-{
-    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
-    const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
-    if (x >= width || y >= height) {
-        return;
-    }
-    if (tile_owner(x / kTile, y / kTile, shard_count) != shard_index) {
-        return;
-    }
-    const size_t pix = (size_t)y * width + x;
-    if (primary[2 * pix].w != 0.f) {
-        return;
-    }
-    float4 mu = mean[pix], var = m2[pix];
-    for (uint32_t s = 0; s < S; s++) {
-        welford(mu, var, make_float4(0.f, 0.f, 0.f, 1.f), first_subframe + s);
-    }
-    mean[pix] = mu;
-    m2[pix] = var;
-}
-
 hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, const uint32_t *pixels,
                                   uint32_t n_entries, const uint32_t *group_order, uint32_t rank_base, bool with_misses,
                                   const float4 *primary, float4 *mean, float4 *m2,
@@ -2546,14 +2563,13 @@ hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, c
                                   uint32_t shard_index, uint32_t shard_count, unsigned long long *bad_samples,
                                   hipStream_t stream)
 {
-    if (n_entries) {
-        hipLaunchKernelGGL(accumulate_list_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, stream, frames,
-                           frame_stride, pixels, n_entries, group_order, rank_base, mean, m2, first_subframe, S, bad_samples);
-    }
-    if (with_misses) {   // (once per batch of subframes, whatever number of chunks the pixel groups are rendered in)
-        const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
-        hipLaunchKernelGGL(accumulate_miss_kernel, grid, block, 0, stream, primary, mean, m2, first_subframe, S, width,
-                           height, shard_index, shard_count);
+    const uint32_t list_blocks = (n_entries + 255u) / 256u;
+    // (the misses once per batch of subframes, whatever number of chunks the pixel groups are rendered in)
+    const uint32_t miss_blocks = with_misses ? ((width + 31u) / 32u) * ((height + 7u) / 8u) : 0u;
+    if (list_blocks + miss_blocks != 0u) {
+        hipLaunchKernelGGL(accumulate_list_kernel, dim3(list_blocks + miss_blocks), dim3(256), 0, stream, frames,
+                           frame_stride, pixels, n_entries, group_order, rank_base, mean, m2, first_subframe, S, bad_samples,
+                           list_blocks, primary, width, height, shard_index, shard_count);
     }
     return hipGetLastError();
 }

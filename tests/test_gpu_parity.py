@@ -1364,6 +1364,69 @@ def test_render_ahead_serves_the_display_cadence_bit_exactly(estimator, max_age,
     assert iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_render_ahead_under_random_call_sequences(seed, monkeypatch):
+    """The state machine of render-ahead under calls in any order: enqueued and waited-for batches of random sizes (below and
+    above the render-ahead), waits, display updates, changes of the render-ahead itself, resets.  A twin handle without
+    render-ahead gets the same waited-for subframes; at every point where something waits the two running means are equal
+    bit for bit, and the estimator has never been launched for less than was asked for."""
+    rng = np.random.default_rng(seed)
+    tex = ds.make_procedural_cloud(64)
+    w = h = 96
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    est = seed & 1
+    tr = ds.CloudTracer(tex, width=w, height=h, estimator=est)
+    twin = ds.CloudTracer(tex, width=w, height=h, estimator=est)
+    tr.set_render_ahead(24)
+    done = 0          # subframes asked of `tr`
+    twin_done = 0
+
+    def check():
+        nonlocal twin_done
+        if done > twin_done:
+            twin.render_accumulate(twin_done + 1, done - twin_done)
+            twin_done = done
+        assert tr.rendered_subframes() >= done
+        assert np.array_equal(tr.mean(), twin.mean()) and np.array_equal(tr.m2(), twin.m2()), done
+
+    for _ in range(70):
+        op = rng.integers(0, 10)
+        if op <= 4:
+            n = int(rng.integers(1, 12))
+            tr.render_accumulate_async(done + 1, n)
+            done += n
+            if rng.integers(0, 2):
+                tr.tonemap_async(0.4)
+        elif op == 5:
+            n = int(rng.integers(20, 60))             # more than the render-ahead: a launch of its own size
+            tr.render_accumulate_async(done + 1, n)
+            done += n
+        elif op == 6:
+            n = int(rng.integers(1, 40))
+            tr.render_accumulate(done + 1, n)
+            done += n
+            check()
+        elif op == 7:
+            tr.synchronize()
+            check()
+        elif op == 8:
+            tr.set_render_ahead(int(rng.choice([0, 8, 24, 40])))
+            check()
+        else:
+            if rng.integers(0, 3) == 0:
+                tr.reset()
+                twin.reset()
+                done = twin_done = 0
+            else:
+                check()
+    tr.synchronize()
+    check()
+    iv = tr.debug_invariants()
+    tr.close()
+    twin.close()
+    assert iv["armed"] == 1 and iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+
+
 @pytest.mark.parametrize("estimator", [0, 1])
 def test_batches_cut_by_pixel_groups_are_bit_exact(estimator, monkeypatch):
     """A batch whose samples do not fit one scratch region is rendered chunk by chunk of PIXEL GROUPS -- every launch all the

@@ -280,6 +280,17 @@ class CloudTracer:
         check(self.L.ct_rendered_subframes(self.h, C.byref(n)), self.h)
         return int(n.value)
 
+    def set_stop_when_converged(self, cadence: int = 10, min_subframes: int = 100):
+        """ct_set_stop_when_converged: Camera::isConverged tested on the device behind every `cadence`-th subframe; the running
+        mean freezes at the first count that passes (the reference's stopping point, Camera.cpp:179,232-268)."""
+        check(self.L.ct_set_stop_when_converged(self.h, cadence, min_subframes), self.h)
+
+    def converged_at(self):
+        """-> (subframes the image was frozen at or 0, count of the last finished test, its unconverged pixels); never waits."""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+        check(self.L.ct_converged_at(self.h, C.byref(a), C.byref(b), C.byref(c)), self.h)
+        return int(a.value), int(b.value), int(c.value)
+
     def is_converged(self):
         ok, bad = C.c_int32(0), C.c_uint64(0)
         check(self.L.ct_is_converged(self.h, C.byref(ok), C.byref(bad)), self.h)

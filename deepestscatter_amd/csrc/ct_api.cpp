@@ -68,6 +68,7 @@ struct CtHandle_ {
         uint32_t first = 0, S = 0;
         uint32_t rank_base = 0, groups = 0;   // the chunk of pixel groups this launch renders (places in the job order)
         bool with_misses = false;          // its accumulate kernel also accounts for the pixels that miss the box (once per batch)
+        bool last_chunk = true;            // ... and is the last of its batch: the running mean is a whole image again after it
     };
     Slot slots[kMaxRegions];
     int n_regions = 2;                     // regions of the scratch in use
@@ -81,6 +82,12 @@ struct CtHandle_ {
     // for; the running mean follows the calls by M * ahead subframes until something waits (flush: exactly `subframes`).
     uint32_t ahead = 0;
     uint32_t rendered = 0;
+    // Stop-when-converged (ct_set_stop_when_converged): behind the accumulate kernel of every `stop_cadence`-th subframe (from
+    // `stop_min` on) the convergence test runs on the device, and once it holds the accumulate kernels leave the running
+    // mean alone -- Camera::render's `if (!isConverged())` (Camera.cpp:179) without a host round trip per update.
+    // d_freeze: converged_freeze_kernel's state words; freeze_host: their first four, copied back after every test (pinned).
+    uint32_t stop_cadence = 0, stop_min = 100;
+    uint32_t *d_freeze = nullptr, *freeze_host = nullptr;
     uint32_t *cont[2] = { nullptr, nullptr }; // suspended paths: launch k writes cont[k & 1], launch k+1 reads it
     uint64_t launch_no = 0;                // estimator launches enqueued so far
     bool cont_live = false;                // the last launch may have suspended paths: the next one resumes them
@@ -335,7 +342,7 @@ static void release(CtHandle h)
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_group_rank, h->d_group_order, h->d_job_group, h->d_job_sub, h->d_queue,
-                     h->d_counters, h->d_colsum, h->d_avg, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
+                     h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
         if (p) {
             hipFree(p);
@@ -360,6 +367,9 @@ static void release(CtHandle h)
         if (e) {
             hipEventDestroy(e);
         }
+    }
+    if (h->freeze_host) {
+        hipHostFree(h->freeze_host);
     }
     if (h->own_stream) {
         hipStreamDestroy(h->own_stream);
@@ -844,6 +854,10 @@ static int create_impl(const CtScene *s, CtHandle h)
         }
     }
     HIPCHK(h, dmalloc(&h->d_counters, kCounterCount + 1 + kStatCount));
+    HIPCHK(h, dmalloc(&h->d_freeze, 8));
+    HIPCHK(h, hipMemsetAsync(h->d_freeze, 0, 8 * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipHostMalloc((void **)&h->freeze_host, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    memset(h->freeze_host, 0, 4 * sizeof(uint32_t));
     HIPCHK(h, hipMemsetAsync(h->d_frame, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_mean, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_m2, 0, pixels * sizeof(float4), h->stream));
@@ -1415,25 +1429,56 @@ static int collect(CtHandle h, CtHandle_::Slot &sl)
     return CT_OK;
 }
 
-// The accumulate kernel(s) for subframes [sl.acc_done, sl.acc_done + n) of a slot's batch.
+// The convergence test on the running mean after `subframes` subframes, and its outcome copied to where the host can
+// read it without waiting (ct_converged_at).
+static int enqueue_convergence_test(CtHandle h, uint32_t subframes)
+{
+    HIPCHK(h, launch_converged_freeze(h->d_mean, h->d_m2, subframes, (uint64_t)h->scene.width * h->scene.height, 500u /* Camera.cpp:267 */,
+                                      h->d_freeze, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->freeze_host, h->d_freeze, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    return CT_OK;
+}
+
+// The accumulate kernel(s) for subframes [sl.acc_done, sl.acc_done + n) of a slot's batch.  With stop-when-converged they
+// are cut at the multiples of its cadence and each is followed by the test (a batch rendered in several chunks of pixel
+// groups is a whole image only after its last chunk: it is tested there, if it ends on a multiple).
 static int enqueue_accumulate(CtHandle h, CtHandle_::Slot &sl, const float4 *frames, bool dense, uint32_t n)
 {
     const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
-    const uint32_t off = sl.acc_done;
+    const bool chunked = !(simple || dense) && h->n_chunks > 1;
+    const uint32_t cadence = h->stop_cadence;
+    const uint32_t *frozen = cadence ? h->d_freeze : nullptr;
     HIPCHK(h, hipEventRecord(sl.ev_acc0, h->stream));
-    if (simple || dense) {
-        HIPCHK(h, launch_accumulate_batch(frames + (size_t)off * h->scene.width * h->scene.height, h->d_mean, h->d_m2, sl.first + off, n,
-                                          h->scene.width, h->scene.height, h->scene.shard_index, h->scene.shard_count,
-                                          h->d_counters + 8, h->stream));
-    } else {
-        HIPCHK(h, launch_accumulate_list(frames + (size_t)off * frame_stride(h), (uint32_t)frame_stride(h), h->d_pixels, sl.groups * 64u,
-                                         h->n_chunks <= 1 ? nullptr : h->d_group_order, sl.rank_base,
-                                         sl.with_misses, h->d_primary, h->d_mean, h->d_m2, sl.first + off, n, h->scene.width,
-                                         h->scene.height, h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, h->stream));
+    while (n != 0u) {
+        const uint32_t off = sl.acc_done, next = sl.first + off;   // (next: the subframe id of the first sample of this piece)
+        uint32_t piece = n;
+        if (cadence && !chunked) {
+            piece = std::min(n, cadence - (next - 1u) % cadence);
+        }
+        if (simple || dense) {
+            HIPCHK(h, launch_accumulate_batch(frames + (size_t)off * h->scene.width * h->scene.height, h->d_mean, h->d_m2, next, piece,
+                                              h->scene.width, h->scene.height, h->scene.shard_index, h->scene.shard_count,
+                                              h->d_counters + 8, frozen, h->stream));
+        } else {
+            HIPCHK(h, launch_accumulate_list(frames + (size_t)off * frame_stride(h), (uint32_t)frame_stride(h), h->d_pixels, sl.groups * 64u,
+                                             h->n_chunks <= 1 ? nullptr : h->d_group_order, sl.rank_base,
+                                             sl.with_misses, h->d_primary, h->d_mean, h->d_m2, next, piece, h->scene.width,
+                                             h->scene.height, h->scene.shard_index, h->scene.shard_count, h->d_counters + 8, frozen,
+                                             h->stream));
+        }
+        sl.acc_done += piece;
+        n -= piece;
+        const uint32_t upto = sl.first + sl.acc_done - 1u;
+        const bool whole_image = !chunked || (sl.last_chunk && sl.acc_done == sl.S);
+        if (cadence && whole_image && upto % cadence == 0u && upto >= h->stop_min) {
+            const int rc = enqueue_convergence_test(h, upto);
+            if (rc != CT_OK) {
+                return rc;
+            }
+        }
     }
     HIPCHK(h, hipEventRecord(sl.ev_acc1, h->stream));   // (of several partial accumulates the last one is the one whose time is booked)
     sl.accumulated = true;
-    sl.acc_done += n;
     return CT_OK;
 }
 
@@ -1618,6 +1663,7 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     sl.rank_base = rank_base;
     sl.groups = chunk_n;
     sl.with_misses = chunk == 0;
+    sl.last_chunk = simple || dense || chunk + 1u >= std::max(h->n_chunks, 1u);
     sl.pending = true;
     sl.accumulated = false;
     sl.awaits_accumulate = false;
@@ -1824,7 +1870,14 @@ extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *fram
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     // (no alpha check here: the caller may accumulate frames of its own)
     HIPCHK(h, launch_accumulate_batch(src, h->d_mean, h->d_m2, subframe_id, 1, h->scene.width, h->scene.height,
-                                      h->scene.shard_index, h->scene.shard_count, nullptr, h->stream));
+                                      h->scene.shard_index, h->scene.shard_count, nullptr, h->stop_cadence ? h->d_freeze : nullptr,
+                                      h->stream));
+    if (h->stop_cadence && subframe_id % h->stop_cadence == 0u && subframe_id >= h->stop_min) {
+        const int rc = enqueue_convergence_test(h, subframe_id);
+        if (rc != CT_OK) {
+            return rc;
+        }
+    }
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev[2]));
     float ms = 0;
@@ -2010,6 +2063,38 @@ extern "C" int ct_set_render_ahead(CtHandle h, uint32_t subframes)
     }
     discard_ahead(h);
     h->ahead = subframes;
+    return CT_OK;
+}
+
+extern "C" int ct_set_stop_when_converged(CtHandle h, uint32_t cadence, uint32_t min_subframes)
+{
+    NEED(h);
+    if (cadence != 0u && h->scene.shard_count > 1u) {
+        return fail(h, CT_E_INVAL, "stop-when-converged is a whole-frame decision: this handle renders shard %u of %u "
+                                   "(test the merged frame with ct_is_converged_buffers)", h->scene.shard_index, h->scene.shard_count);
+    }
+    h->stop_cadence = cadence;
+    h->stop_min = min_subframes;
+    HIPCHK(h, hipMemsetAsync(h->d_freeze, 0, 8 * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memset(h->freeze_host, 0, 4 * sizeof(uint32_t));
+    return CT_OK;
+}
+
+extern "C" int ct_converged_at(CtHandle h, uint32_t *subframes_out, uint32_t *tested_at_out, uint64_t *unconverged_pixels_out)
+{
+    NEED_NOFLUSH(h);
+    // (written by the copies that follow the tests in stream order; read without waiting)
+    const volatile uint32_t *st = h->freeze_host;
+    if (subframes_out) {
+        *subframes_out = st[0];
+    }
+    if (tested_at_out) {
+        *tested_at_out = st[1];
+    }
+    if (unconverged_pixels_out) {
+        *unconverged_pixels_out = st[2];
+    }
     return CT_OK;
 }
 
@@ -2282,7 +2367,9 @@ extern "C" int ct_reset(CtHandle h)
     HIPCHK(h, hipMemsetAsync(h->d_mean, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_m2, 0, pixels * sizeof(float4), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, (kCounterCount + 1 + kStatCount) * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_freeze, 0, 8 * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    memset(h->freeze_host, 0, 4 * sizeof(uint32_t));
     h->subframes = 0;
     discard_ahead(h);
     h->render_ms = h->accum_ms = 0;
@@ -2362,7 +2449,9 @@ static int converged_impl(CtHandle h, const float4 *mean, const float4 *m2, uint
 extern "C" int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unconverged_pixels_out)
 {
     NEED(h);
-    return converged_impl(h, h->d_mean, h->d_m2, h->subframes, converged_out, unconverged_pixels_out);
+    // (a running mean that stop-when-converged froze is the image after that many subframes, whatever was asked for since)
+    const uint32_t frozen_at = h->stop_cadence ? h->freeze_host[0] : 0u;
+    return converged_impl(h, h->d_mean, h->d_m2, frozen_at ? frozen_at : h->subframes, converged_out, unconverged_pixels_out);
 }
 
 extern "C" int ct_is_converged_buffers(CtHandle h, const float *mean_rgba_dev, const float *m2_rgba_dev, uint32_t subframes,

@@ -152,17 +152,20 @@ hipError_t launch_render_simple(const DevScene &sc, const BatchArgs &ba, uint32_
                                 uint32_t shard_count, hipStream_t stream);
 hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
                                    uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
-                                   uint32_t shard_count, unsigned long long *bad_samples, hipStream_t stream);
+                                   uint32_t shard_count, unsigned long long *bad_samples, const uint32_t *frozen,
+                                   hipStream_t stream);
 hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, const uint32_t *pixels,
                                   uint32_t n_entries, const uint32_t *group_order, uint32_t rank_base, bool with_misses,
                                   const float4 *primary, float4 *mean, float4 *m2,
                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
                                   uint32_t shard_index, uint32_t shard_count, unsigned long long *bad_samples,
-                                  hipStream_t stream);
+                                  const uint32_t *frozen, hipStream_t stream);
 hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure,
                            float *column_sums, float *avg, uchar4 *screen, uint32_t *generation, hipStream_t stream);
 hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,
                             unsigned long long *unconverged, hipStream_t stream);
+hipError_t launch_converged_freeze(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,
+                                   uint32_t limit, uint32_t *state, hipStream_t stream);
 hipError_t launch_cdf_selftest(const float *cdf, const uint16_t *guide, uint32_t first_u24, uint32_t count,
                                uint32_t *k_out, hipStream_t stream);
 hipError_t launch_math_selftest(int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out, hipStream_t stream);

@@ -2469,8 +2469,12 @@ __global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__r
                                                                uint32_t first_subframe, uint32_t S, uint32_t width,
                                                                uint32_t height, uint32_t shard_index,
                                                                uint32_t shard_count,
-                                                               unsigned long long *__restrict__ bad_samples)
+                                                               unsigned long long *__restrict__ bad_samples,
+                                                               const uint32_t *__restrict__ frozen)
 {
+    if (frozen && *frozen != 0u) {
+        return;   // the image has converged (converged_freeze_kernel): the running mean stays as it is
+    }
     const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
     const uint32_t y = blockIdx.y * 8u + (threadIdx.x >> 5);
     if (x >= width || y >= height) {
@@ -2497,11 +2501,12 @@ __global__ __launch_bounds__(256) void accumulate_batch_kernel(const float4 *__r
 
 hipError_t launch_accumulate_batch(const float4 *frames, float4 *mean, float4 *m2, uint32_t first_subframe,
                                    uint32_t S, uint32_t width, uint32_t height, uint32_t shard_index,
-                                   uint32_t shard_count, unsigned long long *bad_samples, hipStream_t stream)
+                                   uint32_t shard_count, unsigned long long *bad_samples, const uint32_t *frozen,
+                                   hipStream_t stream)
 {
     const dim3 grid((width + 31) / 32, (height + 7) / 8), block(256);
     hipLaunchKernelGGL(accumulate_batch_kernel, grid, block, 0, stream, frames, mean, m2, first_subframe, S, width,
-                       height, shard_index, shard_count, bad_samples);
+                       height, shard_index, shard_count, bad_samples, frozen);
     return hipGetLastError();
 }
 
@@ -2517,8 +2522,11 @@ __global__ __launch_bounds__(256) void accumulate_list_kernel(const float4 *__re
                                                               unsigned long long *__restrict__ bad_samples,
                                                               uint32_t list_blocks, const float4 *__restrict__ primary,
                                                               uint32_t width, uint32_t height, uint32_t shard_index,
-                                                              uint32_t shard_count)
+                                                              uint32_t shard_count, const uint32_t *__restrict__ frozen)
 {
+    if (frozen && *frozen != 0u) {
+        return;   // the image has converged (converged_freeze_kernel): the running mean stays as it is
+    }
     if (blockIdx.x >= list_blocks) {
         const uint32_t m = blockIdx.x - list_blocks, gx = (width + 31u) / 32u;
         const uint32_t x = (m % gx) * 32u + (threadIdx.x & 31u);
@@ -2586,7 +2594,7 @@ hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, c
                                   const float4 *primary, float4 *mean, float4 *m2,
                                   uint32_t first_subframe, uint32_t S, uint32_t width, uint32_t height,
                                   uint32_t shard_index, uint32_t shard_count, unsigned long long *bad_samples,
-                                  hipStream_t stream)
+                                  const uint32_t *frozen, hipStream_t stream)
 {
     const uint32_t list_blocks = (n_entries + 255u) / 256u;
     // (the misses once per batch of subframes, whatever number of chunks the pixel groups are rendered in)
@@ -2594,7 +2602,7 @@ hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, c
     if (list_blocks + miss_blocks != 0u) {
         hipLaunchKernelGGL(accumulate_list_kernel, dim3(list_blocks + miss_blocks), dim3(256), 0, stream, frames,
                            frame_stride, pixels, n_entries, group_order, rank_base, mean, m2, first_subframe, S, bad_samples,
-                           list_blocks, primary, width, height, shard_index, shard_count);
+                           list_blocks, primary, width, height, shard_index, shard_count, frozen);
     }
     return hipGetLastError();
 }
@@ -2750,29 +2758,109 @@ hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, 
 // =============================================================================================
 // Camera::isConverged (Camera.cpp:232-268), channel x only; counts pixels outside the interval.
 // =============================================================================================
-__global__ void converged_kernel(const float4 *__restrict__ mean, const float4 *__restrict__ m2,
-                                 uint32_t subframe_id, uint64_t pixels, unsigned long long *unconverged)
+__global__ __launch_bounds__(1024) void converged_kernel(const float4 *__restrict__ mean, const float4 *__restrict__ m2,
+                                                         uint32_t subframe_id, uint64_t pixels, unsigned long long *unconverged)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool bad = false;
-    if (i < pixels) {
-        const float N = (float)subframe_id;
+    // (one block per CU and one atomic per block: a wave's worth of pixels per atomic was 16 k atomics on one address, 0.5 ms)
+    const float N = (float)subframe_id;
+    int bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (uint64_t)gridDim.x * blockDim.x) {
         const float sigma = sqrtf(m2[i].x / N);
         const float abs_ci = 1.96f * sigma / sqrtf(N);
         const float rel_ci = abs_ci / (mean[i].x + 1.1920929e-07f);
-        bad = !(rel_ci < 0.02f || abs_ci < 1e-2f);
+        bad += !(rel_ci < 0.02f || abs_ci < 1e-2f) ? 1 : 0;
     }
-    const uint64_t mask = __builtin_amdgcn_ballot_w64(bad);
-    if ((threadIdx.x & 63u) == 0 && mask != 0) {
-        atomicAdd(unconverged, (unsigned long long)__builtin_popcountll(mask));
+    __shared__ int block_bad;
+    if (threadIdx.x == 0) {
+        block_bad = 0;
     }
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bad += __shfl_xor(bad, off);
+    }
+    if ((threadIdx.x & 63u) == 0u && bad != 0) {
+        atomicAdd(&block_bad, bad);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && block_bad != 0) {
+        atomicAdd(unconverged, (unsigned long long)block_bad);
+    }
+}
+
+static unsigned converged_grid(uint64_t pixels)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        cus = 64;
+    }
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus, (pixels + 1023) / 1024));
 }
 
 hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,
                             unsigned long long *unconverged, hipStream_t stream)
 {
-    hipLaunchKernelGGL(converged_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, mean, m2,
-                       subframe_id, pixels, unconverged);
+    hipLaunchKernelGGL(converged_kernel, dim3(converged_grid(pixels)), dim3(1024), 0, stream, mean, m2, subframe_id, pixels, unconverged);
+    return hipGetLastError();
+}
+
+// The same test enqueued behind the accumulate kernel of every `cadence`-th subframe (ct_set_stop_when_converged), with the
+// reference's decision taken on the device: Camera::render tests isConverged() before every update of 10 subframes and stops
+// at the first count N >= 100 with fewer than 500 pixels outside the interval (Camera.cpp:179, 232-268).  The last block to
+// finish writes state[0] = N when that holds, and from then on the accumulate kernels leave the running mean alone: the
+// buffers keep the reference's final image although the host, which does not wait, has enqueued more.
+// state: [0] frozen at N (0 = running)  [1] last count tested  [2] pixels outside the interval then  [4,5] one 64-bit word:
+// blocks finished << 32 | pixels outside the interval so far.  ONE atomic per block and a grid of one block per CU: with a
+// block per 256 pixels the 8192 atomics on one line took 0.24 ms (35 M/s), twenty times the reading of the two buffers.
+__global__ __launch_bounds__(1024) void converged_freeze_kernel(const float4 *__restrict__ mean, const float4 *__restrict__ m2,
+                                                                uint32_t subframe_id, uint64_t pixels, uint32_t limit,
+                                                                uint32_t *state)
+{
+    if (__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        return;   // (set by an earlier kernel of this stream: every block reads the same)
+    }
+    const float N = (float)subframe_id;
+    int bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float sigma = sqrtf(m2[i].x / N);
+        const float abs_ci = 1.96f * sigma / sqrtf(N);
+        const float rel_ci = abs_ci / (mean[i].x + 1.1920929e-07f);
+        bad += !(rel_ci < 0.02f || abs_ci < 1e-2f) ? 1 : 0;
+    }
+    __shared__ int block_bad;
+    if (threadIdx.x == 0) {
+        block_bad = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bad += __shfl_xor(bad, off);
+    }
+    if ((threadIdx.x & 63u) == 0u && bad != 0) {
+        atomicAdd(&block_bad, bad);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *word = (unsigned long long *)(state + 4);
+        const unsigned long long old = __hip_atomic_fetch_add(word, (1ull << 32) | (unsigned long long)(uint32_t)block_bad, __ATOMIC_ACQ_REL,
+                                                              __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(old >> 32) == gridDim.x - 1u) {
+            const uint32_t total = (uint32_t)old + (uint32_t)block_bad;
+            __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            state[1] = subframe_id;
+            state[2] = total;
+            if (total < limit) {
+                __hip_atomic_store(state, subframe_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+hipError_t launch_converged_freeze(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,
+                                   uint32_t limit, uint32_t *state, hipStream_t stream)
+{
+    hipLaunchKernelGGL(converged_freeze_kernel, dim3(converged_grid(pixels)), dim3(1024), 0, stream, mean, m2, subframe_id, pixels, limit,
+                       state);
     return hipGetLastError();
 }
 

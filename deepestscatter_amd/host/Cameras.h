@@ -106,6 +106,9 @@ namespace DeepestScatter
         {
             subframeId = 0;
             context->resetAccumulation();
+            // headless: the test the reference makes before every update of 10 (:179, :232-268) runs on the device behind every
+            // 10th subframe's accumulate kernel and freezes the image where the reference's loop would stop
+            deviceStops = headless && fused && context->stopWhenConverged(subframesPerUpdate, 100);
         }
 
         bool isCompleted() override { return completed; }
@@ -121,6 +124,8 @@ namespace DeepestScatter
         bool fused = true;              // one ct_render_accumulate per update instead of 2 launches per subframe
         bool headless = false;          // no display: enqueue the batches, read the buffers only where the reference saves
         bool completed = true;          // Camera.h:55
+
+        bool deviceStops = false;       // the convergence test runs on the device (ct_set_stop_when_converged)
 
         uint32_t getSubframeId() const { return subframeId; }
         const std::vector<uint8_t>& getScreen() const { return screen; }
@@ -163,12 +168,27 @@ namespace DeepestScatter
         {
             // headless: nobody looks at the screen between saves, so batches are enqueued (a launch hands its
             // unfinished paths to the next one instead of ending with a tail) and the buffers are only read --
-            // convergence test, tonemap, save -- every 40 subframes, where the reference saves (:211-214).  The reference
-            // tests convergence at every update (10 subframes): headless may stop up to 30 subframes later; the images it
-            // saves at multiples of 40 are the reference's, the final one has those extra samples (headless = false stops
-            // exactly where the reference does)
+            // tonemap, save -- every 40 subframes, where the reference saves (:211-214).  The reference tests convergence
+            // before every update of 10 subframes: the device does that behind every 10th subframe (deviceStops) and freezes
+            // the image at the count where the reference's loop stops; the host learns of it at the next save point, takes
+            // that count and that image, and is done -- the subframes enqueued meanwhile were rendered and dropped.  (A group
+            // of GPUs tests its merged frame at the save points only and may stop up to 30 subframes later.)
             const bool look = !headless || subframeId % 40 == 0;
-            if (!(look && isConverged()) && !(maxSubframes && subframeId >= maxSubframes))
+            if (deviceStops && look && subframeId >= 100)
+            {
+                uint64_t left = 0;
+                const uint32_t at = context->convergedAt(left);   // (the tonemap of this save point has waited for everything)
+                if (at != 0)
+                {
+                    std::cout << "Converged: " << (uint64_t)width * height - left << "/" << (uint64_t)width * height << " --- " << left << "left" << std::endl;
+                    subframeId = at;
+                    completed = true;
+                    std::cout << "rendering subframe " << subframeId << std::endl;
+                    saveToDisk();
+                    return;
+                }
+            }
+            if (!(look && !deviceStops && isConverged()) && !(maxSubframes && subframeId >= maxSubframes))
             {
                 // headless: one batch up to the next point where anything is read (at 1024^2 a batch of 40 costs 15.4 ms where
                 // four of 10 cost 18.5: a short launch has every pixel group in flight at once and misses L2 half again as
@@ -208,6 +228,14 @@ namespace DeepestScatter
             }
             else
             {
+                if (deviceStops)
+                {
+                    // (the subframe limit came first -- or did it?  the image may have frozen since the last save point)
+                    uint64_t left = 0;
+                    context->wait();
+                    const uint32_t at = context->convergedAt(left);
+                    if (at != 0) subframeId = at;
+                }
                 completed = true;
                 std::cout << "rendering subframe " << subframeId << std::endl;
                 saveToDisk();

@@ -86,6 +86,21 @@ namespace DeepestScatter
             if (group) checkGroup(ct_group_tonemap(group, exposure, screen, nullptr), group, "ct_group_tonemap");
             else check(ct_tonemap(handle, exposure, screen, nullptr), handle, "ct_tonemap");
         }
+        // Camera::render's isConverged() before every update, decided on the device (ct_set_stop_when_converged): a single
+        // handle only -- a group tests its merged frame where it is read
+        bool stopWhenConverged(uint32_t cadence, uint32_t minSubframes)
+        {
+            if (group || !handle) return false;
+            check(ct_set_stop_when_converged(handle, cadence, minSubframes), handle, "ct_set_stop_when_converged");
+            return true;
+        }
+        void wait() { if (handle) check(ct_synchronize(handle), handle, "ct_synchronize"); }
+        uint32_t convergedAt(uint64_t& left)                                       // never waits
+        {
+            uint32_t at = 0, tested = 0;
+            check(ct_converged_at(handle, &at, &tested, &left), handle, "ct_converged_at");
+            return at;
+        }
         bool isConverged(uint64_t& left)
         {
             int32_t converged = 0;

@@ -246,6 +246,22 @@ CT_API int ct_tonemap_async(CtHandle h, float exposure);
  * fewer than 500 pixels are outside the 95 % interval; *unconverged_pixels_out optional. */
 CT_API int ct_is_converged(CtHandle h, int32_t *converged_out, uint64_t *unconverged_pixels_out);
 
+/* Camera::render's `if (!isConverged())` (Camera.cpp:179) without a host round trip per update.  With cadence > 0 the
+ * library enqueues the test of Camera::isConverged behind the accumulate kernel of every cadence-th subframe from
+ * min_subframes on (the reference: 10 and 100, Camera.cpp:189,234) -- the accumulate kernels are cut at those counts, whatever
+ * the sizes of the calls, render-ahead included -- and takes the reference's decision on the device: at the first such count
+ * with fewer than 500 pixels outside the interval the running mean and M2 are FROZEN; every later accumulate kernel leaves
+ * them alone.  So a host that enqueues update after update (ct_render_accumulate_async + ct_tonemap_async) and looks at
+ * ct_converged_at now and then -- it never waits -- ends with exactly the image, and the subframe count, at which the
+ * reference's loop stops; what it enqueued beyond that point is rendered and dropped.  ct_converged_at: *subframes_out = the
+ * count the image was frozen at (0 = still running), *tested_at_out / *unconverged_pixels_out = the last test that has
+ * finished (any of them may be NULL); up to date after ct_synchronize.  ct_reset and ct_set_stop_when_converged clear the
+ * state; ct_is_converged after a freeze tests the frozen image with its own count.  A batch rendered in several chunks of
+ * pixel groups (it did not fit the scratch) is tested at its end only.  Whole frames only: CT_E_INVAL on a shard of a
+ * multi-GPU job (test the merged frame with ct_is_converged_buffers).  cadence 0 (the default) turns it off. */
+CT_API int ct_set_stop_when_converged(CtHandle h, uint32_t cadence, uint32_t min_subframes);
+CT_API int ct_converged_at(CtHandle h, uint32_t *subframes_out, uint32_t *tested_at_out, uint64_t *unconverged_pixels_out);
+
 /* The same two on caller-owned device buffers of W*H float4 each: the frame a multi-GPU reduce merged on rank 0
  * (every shard's handle holds its own tiles and zeros elsewhere; the SUM of the shards' CT_BUF_MEAN / CT_BUF_M2 is
  * the whole image).  reinhard.cu:44-55 sums the luminance of the WHOLE frame in a fixed order

@@ -366,6 +366,32 @@ def test_cpp_host_cli_matches_python_path(tmp_path):
     assert bad.returncode == 1 and "Invalid Render Mode" in bad.stdout      # CloudMaterial.cpp:62 / main.cpp:65-76
 
 
+@pytest.mark.gpu
+def test_cpp_host_runs_until_converged_and_stops_where_the_reference_loop_stops(tmp_path):
+    """`cloudtrace` without --spp renders until Camera::isConverged holds (Camera.cpp:179).  The headless Camera enqueues
+    batches up to its save points and leaves the test to the device (ct_set_stop_when_converged); `--display` runs the
+    reference's own loop -- 10 subframes, tonemap, test, every call waited for.  Same stopping count (100: the first test,
+    not a save point, so the headless run learns of it at 120 and has rendered 20 subframes for nothing), same image."""
+    import subprocess
+    from deepestscatter_amd import build, exr
+    cli = build.build_cli()
+    tex = ds.make_procedural_cloud(32)
+    tr = ds.CloudTracer(tex, width=40, height=24, light_direction=ds.LIGHT_DIRECTIONS["Back"])
+    tr.render_accumulate(1, 100)
+    assert tr.is_converged()[0]
+    want = tr.mean()[..., :3]
+    tr.close()
+    for extra in ([], ["--display"]):
+        out = tmp_path / ("d" if extra else "h")
+        out.mkdir()
+        r = subprocess.run([str(cli), "procedural:32", "--size", "40x24", "--light", "Back", "--out", str(out), *extra],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [l for l in r.stdout.splitlines() if l.startswith("rendering subframe")]
+        assert lines[-1] == "rendering subframe 100", lines[-3:]
+        assert np.array_equal(exr.read_exr(out / "procedural_32.Back.PT.exr"), want)
+
+
 # ---- DELTA estimator (Woodcock tracking; oracle twin: delta_flight in oracle/ct_oracle.c) -------------
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_delta_estimator_bit_exact_vs_oracle(mode):
@@ -1425,6 +1451,89 @@ def test_render_ahead_under_random_call_sequences(seed, monkeypatch):
     tr.close()
     twin.close()
     assert iv["armed"] == 1 and iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+
+
+def _pixels_outside_the_interval(mean, m2, n):
+    """Camera::isConverged's count (Camera.cpp:244-262) in float32, for any subframe count."""
+    N = np.float32(n)
+    sigma = np.sqrt(m2[..., 0] / N)
+    a = np.float32(1.96) * sigma / np.sqrt(N)
+    r = a / (mean[..., 0] + np.float32(1.1920929e-07))
+    return int((~((r < np.float32(0.02)) | (a < np.float32(1e-2)))).sum())
+
+
+@pytest.mark.parametrize("case", ["crossing", "first_test", "never", "crossing_render_ahead", "first_test_render_ahead", "chunked"])
+def test_stop_when_converged_freezes_the_reference_image(case, monkeypatch):
+    """Camera::render tests isConverged() before every update of 10 subframes and stops at the first count that passes
+    (Camera.cpp:179, 232-268).  ct_set_stop_when_converged takes that decision on the device behind every 10th subframe's
+    accumulate kernel, so a host that only enqueues ends with the reference loop's image and count: compared with a twin that
+    runs the reference's control flow with waited-for calls -- a count that fails and the next one that passes (single
+    scatter, tests from 10 subframes on), the reference's first test at 100 passing, a frame that never converges, the same
+    with render-ahead (accumulates cut at the multiples of 10), and a batch rendered in chunks (tested at its end)."""
+    ahead = 40 if case.endswith("render_ahead") else 0
+    kind = case.replace("_render_ahead", "")
+    if kind == "crossing":
+        vol, size, mode, first_test, updates = 64, 1024, 2, 10, 6
+    elif kind == "first_test":
+        vol, size, mode, first_test, updates = 64, 48, 0, 100, 14
+    elif kind == "never":
+        vol, size, mode, first_test, updates = 64, 96, 0, 100, 16
+    else:
+        vol, size, mode, first_test, updates = 64, 160, 2, 10, 5
+        monkeypatch.setenv("CT_SCRATCH_MIB", "1")
+    tex = ds.make_procedural_cloud(vol)
+    twin = ds.CloudTracer(tex, width=size, height=size, mode=mode)
+    n, stopped, tally = 0, 0, {}
+    while n < updates * 10:
+        if n >= first_test:
+            tally[n] = _pixels_outside_the_interval(twin.mean(), twin.m2(), n)
+            if n >= 100:
+                assert twin.is_converged() == (tally[n] < 500, tally[n])
+            if tally[n] < 500:
+                stopped = n
+                break
+        twin.render_accumulate(n + 1, 10)
+        n += 10
+    want = (twin.mean(), twin.m2())
+    twin.close()
+    if kind == "crossing":
+        assert stopped == 20 and tally[10] >= 500, tally          # (the case is what its name says)
+    elif kind == "first_test":
+        assert stopped == 100, tally
+    elif kind == "never":
+        assert stopped == 0 and min(tally.values()) >= 500, tally
+
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    tr = ds.CloudTracer(tex, width=size, height=size, mode=mode)
+    tr.set_stop_when_converged(10, first_test)
+    if ahead:
+        tr.set_render_ahead(ahead)
+    for k in range(updates):
+        tr.render_accumulate_async(10 * k + 1, 10)
+        tr.tonemap_async(0.4)
+        tr.converged_at()                                          # (never waits; whatever it says is allowed to be stale)
+    tr.synchronize()
+    frozen_at, tested_at, outside = tr.converged_at()
+    got = (tr.mean(), tr.m2())
+    iv = tr.debug_invariants()
+    if kind == "chunked":
+        # chunk by chunk a batch is a whole image only at its end: every update's end is tested here, so the outcome is the same
+        assert stopped == frozen_at
+    assert frozen_at == stopped, (frozen_at, tested_at, outside, tally)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    if stopped:
+        assert tested_at == stopped and outside == tally[stopped]
+        if stopped >= 100:
+            assert tr.is_converged() == (True, tally[stopped])    # (tests the frozen image with its own count)
+    else:
+        assert tested_at == updates * 10 and outside == _pixels_outside_the_interval(got[0], got[1], tested_at)
+    assert iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+    # a reset starts over
+    tr.reset()
+    assert tr.converged_at() == (0, 0, 0)
+    tr.render_accumulate(1, 10)
+    assert tr.mean().any()
+    tr.close()
 
 
 @pytest.mark.parametrize("estimator", [0, 1])

@@ -12,12 +12,31 @@ sys.path.insert(0, str(ROOT))
 import numpy as np
 
 
-def run(a, spp, updates, tonemap=True, ahead=0):
+def run_reference_loop(a, spp, updates):
+    """Camera::render as the reference runs it, every call waited for: isConverged(), `spp` subframes, tonemap to the host."""
+    import deepestscatter_amd as ds
+    tr = ds.CloudTracer(run.tex, width=a.size, height=a.size, estimator=a.estimator)
+    tr.render_accumulate(1, 30)
+    first = 31
+    for _ in range(4):
+        tr.render_accumulate(first, spp); first += spp
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        tr.is_converged()
+        tr.render_accumulate(first, spp); first += spp
+        tr.tonemap(0.4)
+    dt = time.perf_counter() - t0
+    tr.close()
+    return {"loop": "reference (waited-for: is_converged, render_accumulate, tonemap)", "spp_per_update": spp, "updates": updates,
+            "ms_per_update": dt / updates * 1e3, "Msamples_per_s": a.size * a.size * spp * updates / dt / 1e6}
+
+
+def run(a, spp, updates, tonemap=True, ahead=0, stop=False):
     import deepestscatter_amd as ds
     tex = run.tex
     tr = ds.CloudTracer(tex, width=a.size, height=a.size, estimator=a.estimator)
-    tr.render_accumulate(1, 32)                       # cost-measuring launch of the pose
-    first = 33
+    tr.render_accumulate(1, 30)                       # cost-measuring launch of the pose (updates of 10 then end on multiples of 10)
+    first = 31
     warm = max(4, 64 // spp)
     if ahead:
         # (whole launches in the warm-up and in the timed region: what is timed is what is counted)
@@ -25,6 +44,8 @@ def run(a, spp, updates, tonemap=True, ahead=0):
         per = max(1, ahead // spp)
         warm = 2 * per
         updates = max(per, updates // per * per)
+    if stop:
+        tr.set_stop_when_converged(10, 100)           # the reference's test, on the device behind every 10th subframe
     for _ in range(warm):                             # warm-up: scratch ring, job list for this batch size
         tr.render_accumulate_async(first, spp); first += spp
     tr.synchronize()
@@ -33,11 +54,14 @@ def run(a, spp, updates, tonemap=True, ahead=0):
         tr.render_accumulate_async(first, spp); first += spp
         if tonemap:
             tr.tonemap_async(0.4)
+        if stop:
+            tr.converged_at()
     tr.synchronize()
     dt = time.perf_counter() - t0
     out = {"spp_per_update": spp, "updates": updates, "tonemap_every_update": tonemap, "ms_per_update": dt / updates * 1e3,
            "Msamples_per_s": a.size * a.size * spp * updates / dt / 1e6, "suspended_paths": tr.debug_suspended(),
            "checksum": float(tr.mean().astype(np.float64).sum()), "render_ahead": ahead,
+           "stop_when_converged": (list(tr.converged_at()) if stop else None),
            "asked_subframes": first - 1, "rendered_subframes": tr.rendered_subframes()}
     tr.close()
     return out
@@ -51,6 +75,7 @@ if __name__ == "__main__":
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--ahead", type=int, nargs="*", default=[], help="also with ct_set_render_ahead(N) for every N given")
+    ap.add_argument("--stop", action="store_true", help="also with ct_set_stop_when_converged(10, 100), and the reference's waited-for loop")
     ap.add_argument("--reference-spp", type=int, default=1000, help="the long batch the rate is compared with (0 = skip)")
     a = ap.parse_args()
     import deepestscatter_amd as ds
@@ -65,6 +90,14 @@ if __name__ == "__main__":
                 r = run(a, spp, a.updates, ahead=ahead)
                 print(json.dumps(r), flush=True)
                 res["runs"].append(r)
+        if a.stop:
+            for ahead in [0] + [x for x in a.ahead if x > spp]:
+                r = run(a, spp, a.updates, ahead=ahead, stop=True)
+                print(json.dumps(r), flush=True)
+                res["runs"].append(r)
+            r = run_reference_loop(a, spp, a.updates)
+            print(json.dumps(r), flush=True)
+            res["reference_loop"] = r
     if a.reference_spp:
         r = run(a, a.reference_spp, 2, tonemap=False)
         print("reference", json.dumps(r), flush=True)

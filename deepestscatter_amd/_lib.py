@@ -19,7 +19,7 @@ CT_FLAG_NONE, CT_FLAG_SIMPLE_KERNEL, CT_FLAG_LIGHT_NORMALIZED, CT_FLAG_SPARSE_BR
 # every symbol include/cloudtrace.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ct_create", "ct_destroy", "ct_last_error", "ct_set_stream", "ct_set_camera", "ct_render_subframe",
-    "ct_accumulate", "ct_render_accumulate", "ct_render_accumulate_async", "ct_synchronize", "ct_copy_to_device_async", "ct_point_radiance_launch", "ct_generate_scatter_samples", "ct_collect_descriptors", "ct_reset", "ct_tonemap", "ct_tonemap_async", "ct_set_render_ahead", "ct_rendered_subframes", "ct_set_stop_when_converged", "ct_converged_at", "ct_is_converged", "ct_tonemap_buffer", "ct_is_converged_buffers", "ct_download",
+    "ct_accumulate", "ct_render_accumulate", "ct_render_accumulate_async", "ct_synchronize", "ct_copy_to_device_async", "ct_point_radiance_launch", "ct_generate_scatter_samples", "ct_collect_descriptors", "ct_reset", "ct_tonemap", "ct_tonemap_async", "ct_set_render_ahead", "ct_rendered_subframes", "ct_set_stop_when_converged", "ct_converged_at", "ct_is_converged", "ct_tonemap_buffer", "ct_is_converged_buffers", "ct_download", "ct_upload",
     "ct_buffer_bytes", "ct_copy_to_device", "ct_device_ptr", "ct_subframes", "ct_set_subframes", "ct_counters", "ct_kernel_time",
     "ct_debug_cdf_inversion", "ct_debug_math_selftest", "ct_debug_fetch_probe", "ct_debug_stats", "ct_debug_stats_ex", "ct_debug_suspended", "ct_debug_invariants", "ct_debug_memory", "ct_fetch_counters", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_load_vdb", "ct_generate_mipmaps",
     "ct_tile_owner", "ct_make_procedural_cloud",
@@ -122,6 +122,7 @@ def load():
         "ct_tonemap_buffer": (i32, [vp, vp, f32, vp, C.POINTER(f32)]),
         "ct_is_converged_buffers": (i32, [vp, vp, vp, u32, C.POINTER(i32), C.POINTER(C.c_uint64)]),
         "ct_download": (i32, [vp, i32, vp, C.c_size_t]),
+        "ct_upload": (i32, [vp, i32, vp, C.c_size_t]),
         "ct_buffer_bytes": (i32, [vp, i32, C.POINTER(C.c_size_t)]),
         "ct_copy_to_device": (i32, [vp, i32, vp, C.c_size_t]),
         "ct_copy_to_device_async": (i32, [vp, i32, vp, C.c_size_t]),

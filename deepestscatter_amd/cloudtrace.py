@@ -324,6 +324,26 @@ class CloudTracer:
         check(self.L.ct_download(self.h, which, _p(out), out.nbytes), self.h)
         return out
 
+    def upload(self, which: int, data: np.ndarray):
+        """ct_upload: set the running mean or M2 (checkpoint / resume, with set_subframes)."""
+        a = np.ascontiguousarray(data, np.float32)
+        check(self.L.ct_upload(self.h, which, _p(a), a.nbytes), self.h)
+
+    def save_state(self, path):
+        """(mean, M2, subframe count) -> .npz: everything a progressive render needs to continue exactly."""
+        n = C.c_uint32(0)
+        check(self.L.ct_subframes(self.h, C.byref(n)), self.h)
+        mean, m2 = self.mean(), self.m2()          # (these wait: the count below is what the buffers hold)
+        np.savez(path, mean=mean, m2=m2, subframes=np.uint32(n.value))
+
+    def load_state(self, path) -> int:
+        with np.load(path) as z:
+            self.upload(CT_BUF_MEAN, z["mean"])
+            self.upload(CT_BUF_M2, z["m2"])
+            n = int(z["subframes"])
+        self.set_subframes(n)
+        return n
+
     def mean(self):
         return self.download(CT_BUF_MEAN)
 

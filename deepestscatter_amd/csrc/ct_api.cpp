@@ -2508,6 +2508,27 @@ extern "C" int ct_download(CtHandle h, int32_t which, void *dst_host, size_t dst
     return CT_OK;
 }
 
+extern "C" int ct_upload(CtHandle h, int32_t which, const void *src_host, size_t src_bytes)
+{
+    NEED(h);
+    if (which != CT_BUF_MEAN && which != CT_BUF_M2) {
+        return fail(h, CT_E_INVAL, "ct_upload: only the running mean and M2 can be set (buffer %d)", which);
+    }
+    void *p;
+    size_t b = 0;
+    const int rc = buffer_info(h, which, &p, &b);
+    if (rc != CT_OK) {
+        return rc;
+    }
+    if (!src_host || src_bytes != b) {
+        return fail(h, CT_E_INVAL, "ct_upload: need %zu bytes, got %zu", b, src_bytes);
+    }
+    discard_ahead(h);   // (what was rendered ahead belongs to the image that is being replaced)
+    HIPCHK(h, hipMemcpyAsync(p, src_host, b, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CT_OK;
+}
+
 extern "C" int ct_copy_to_device(CtHandle h, int32_t which, void *dst_dev, size_t dst_bytes)
 {
     NEED(h);

@@ -329,6 +329,13 @@ CT_API int ct_collect_descriptors(CtHandle h, const float *positions_host, const
 CT_API int ct_download(CtHandle h, int32_t which /*CtBuffer*/, void *dst_host, size_t dst_bytes);
 CT_API int ct_buffer_bytes(CtHandle h, int32_t which /*CtBuffer*/, size_t *bytes_out);
 
+/* The other direction, for CT_BUF_MEAN and CT_BUF_M2 only: with ct_download and ct_set_subframes this is checkpoint / resume of
+ * a progressive render -- (mean, M2, subframe count) IS its whole state, because a sample's seed is (pixel, subframe id): a
+ * handle that is given the three continues exactly where the saved one was (the reference's own EXR dumps
+ * every 40 subframes, Camera.cpp:211-214, cannot be resumed from -- no variance, no count).  src_bytes must equal
+ * ct_buffer_bytes(); other buffers are CT_E_INVAL. */
+CT_API int ct_upload(CtHandle h, int32_t which /*CtBuffer*/, const void *src_host, size_t src_bytes);
+
 /* Raw device pointer of CT_BUF_MEAN / CT_BUF_M2 / CT_BUF_FRAME / CT_BUF_SCREEN, so a caller can
  * hand the accumulated radiance buffer to a collective (RCCL) without a copy. */
 CT_API int ct_device_ptr(CtHandle h, int32_t which /*CtBuffer*/, void **ptr_out);

@@ -1453,6 +1453,30 @@ def test_render_ahead_under_random_call_sequences(seed, monkeypatch):
     assert iv["armed"] == 1 and iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
 
 
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_checkpoint_and_resume_continue_exactly(estimator, tmp_path):
+    """(mean, M2, subframe count) is the whole state of a progressive render -- a sample's seed is (pixel, subframe id) -- so a
+    fresh handle that is given the three (ct_upload, ct_set_subframes) continues bit for bit where the saved one was.  The
+    reference's EXR dumps (Camera.cpp:211-214) hold neither variance nor count."""
+    tex = ds.make_procedural_cloud(48)
+    w, h = 72, 56
+    a = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+    a.render_accumulate(1, 23)
+    a.save_state(tmp_path / "state.npz")
+    a.render_accumulate(24, 17)
+    want = (a.mean(), a.m2(), a.tonemap(0.4)[0])
+    a.close()
+    b = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+    b.render_accumulate(1, 5)                      # (whatever the handle held before is replaced)
+    assert b.load_state(tmp_path / "state.npz") == 23
+    b.render_accumulate_async(24, 10)
+    b.render_accumulate(34, 7)
+    assert np.array_equal(b.mean(), want[0]) and np.array_equal(b.m2(), want[1]) and np.array_equal(b.tonemap(0.4)[0], want[2])
+    with pytest.raises(_lib.CloudTraceError):
+        b.upload(_lib.CT_BUF_SCREEN, np.zeros((h, w, 4), np.float32))
+    b.close()
+
+
 def _pixels_outside_the_interval(mean, m2, n):
     """Camera::isConverged's count (Camera.cpp:244-262) in float32, for any subframe count."""
     N = np.float32(n)

@@ -135,12 +135,33 @@ def cpu_baseline(ds, tex, ins, width, height, mode, target_s):
     return out
 
 
-def progressive_leg(tr, W, H, first, spp=10, updates=100, ahead=0):
+def reference_loop_leg(tr, W, H, first, spp=10, updates=32):
+    """Camera::render as the reference issues it (Camera.cpp:177-230), every call waited for: isConverged(), `spp` subframes,
+    the tonemap copied to the host.  What the pipelined legs are to be compared with."""
+    for _ in range(2):
+        tr.render_accumulate(first, spp)
+        first += spp
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        tr.is_converged()
+        tr.render_accumulate(first, spp)
+        first += spp
+        tr.tonemap(0.4)
+    dt = time.perf_counter() - t0
+    return {"spp_per_update": spp, "updates": updates, "ms_per_update": dt / updates * 1e3,
+            "value": W * H * spp * updates / dt / 1e6, "unit": "Msamples/s"}, first
+
+
+def progressive_leg(tr, W, H, first, spp=10, updates=100, ahead=0, stop=False):
     """The reference's cadence (Camera::render, Camera.cpp:189-214): `spp` subframes, then the display update.  Enqueued
     batches with ct_tonemap_async behind each; paths and unstarted jobs pass from launch to launch.
     ahead > 0: the same calls with ct_set_render_ahead(ahead) -- launches of `ahead` subframes, every call accumulating and
-    displaying its own share; warm-up and timed region are whole launches, so what is timed is what is counted."""
+    displaying its own share; warm-up and timed region are whole launches, so what is timed is what is counted.
+    stop: with ct_set_stop_when_converged(10, 100) -- the reference's isConverged() before every update, decided on the device
+    behind every 10th subframe (this frame never passes it, so nothing freezes) -- and the host reading ct_converged_at."""
     warm = 8
+    if stop:
+        tr.set_stop_when_converged(10, 100)
     if ahead:
         tr.set_render_ahead(ahead)
         per = max(1, ahead // spp)
@@ -154,10 +175,16 @@ def progressive_leg(tr, W, H, first, spp=10, updates=100, ahead=0):
         tr.render_accumulate_async(first, spp)
         tr.tonemap_async(0.4)
         first += spp
+        if stop:
+            tr.converged_at()
     tr.synchronize()
     dt = time.perf_counter() - t0
     out = {"spp_per_update": spp, "updates": updates, "tonemap_every_update": True, "ms_per_update": dt / updates * 1e3,
            "value": W * H * spp * updates / dt / 1e6, "unit": "Msamples/s"}
+    if stop:
+        frozen_at, tested_at, outside = tr.converged_at()
+        out["convergence_test_on_device"] = {"every": 10, "frozen_at": frozen_at, "last_tested_at": tested_at, "pixels_outside_the_interval": outside}
+        tr.set_stop_when_converged(0, 100)
     if ahead:
         out["render_ahead_subframes"] = ahead
         out["rendered_not_asked_for"] = tr.rendered_subframes() - (first - 1)
@@ -574,9 +601,13 @@ def main():
         prog["fraction_of_headline"] = prog["value"] / value
         # the same calls served by launches of 80 subframes (ct_set_render_ahead): every update still shows the reference's
         # image for its subframe count, 80 subframes later
-        ahead, nxt = progressive_leg(tr, W, H, nxt, ahead=80)
+        ahead, nxt = progressive_leg(tr, W, H, nxt, ahead=80, stop=True)
         ahead["fraction_of_headline"] = ahead["value"] / value
         prog["with_render_ahead"] = ahead
+        # ... and the reference's loop as the reference issues it: every call waited for
+        waited, nxt = reference_loop_leg(tr, W, H, nxt)
+        waited["fraction_of_headline"] = waited["value"] / value
+        prog["reference_loop_every_call_waited_for"] = waited
         out["progressive_10spp"] = prog
     if rank == 0 and world == 1 and args.estimator == 0 and not args.simple_kernel and not args.no_delta_leg:
         out["delta_estimator"] = delta_leg(ds, tex, W, H, args.mode, S, max(args.steps, 1))

@@ -15,7 +15,7 @@ import numpy as np
 def run_reference_loop(a, spp, updates):
     """Camera::render as the reference runs it, every call waited for: isConverged(), `spp` subframes, tonemap to the host."""
     import deepestscatter_amd as ds
-    tr = ds.CloudTracer(run.tex, width=a.size, height=a.size, estimator=a.estimator)
+    tr = ds.CloudTracer(run.tex, width=a.size, height=(a.height or a.size), estimator=a.estimator)
     tr.render_accumulate(1, 30)
     first = 31
     for _ in range(4):
@@ -28,13 +28,13 @@ def run_reference_loop(a, spp, updates):
     dt = time.perf_counter() - t0
     tr.close()
     return {"loop": "reference (waited-for: is_converged, render_accumulate, tonemap)", "spp_per_update": spp, "updates": updates,
-            "ms_per_update": dt / updates * 1e3, "Msamples_per_s": a.size * a.size * spp * updates / dt / 1e6}
+            "ms_per_update": dt / updates * 1e3, "Msamples_per_s": a.size * (a.height or a.size) * spp * updates / dt / 1e6}
 
 
 def run(a, spp, updates, tonemap=True, ahead=0, stop=False):
     import deepestscatter_amd as ds
     tex = run.tex
-    tr = ds.CloudTracer(tex, width=a.size, height=a.size, estimator=a.estimator)
+    tr = ds.CloudTracer(tex, width=a.size, height=(a.height or a.size), estimator=a.estimator)
     tr.render_accumulate(1, 30)                       # cost-measuring launch of the pose (updates of 10 then end on multiples of 10)
     first = 31
     warm = max(4, 64 // spp)
@@ -59,7 +59,7 @@ def run(a, spp, updates, tonemap=True, ahead=0, stop=False):
     tr.synchronize()
     dt = time.perf_counter() - t0
     out = {"spp_per_update": spp, "updates": updates, "tonemap_every_update": tonemap, "ms_per_update": dt / updates * 1e3,
-           "Msamples_per_s": a.size * a.size * spp * updates / dt / 1e6, "suspended_paths": tr.debug_suspended(),
+           "Msamples_per_s": a.size * (a.height or a.size) * spp * updates / dt / 1e6, "suspended_paths": tr.debug_suspended(),
            "checksum": float(tr.mean().astype(np.float64).sum()), "render_ahead": ahead,
            "stop_when_converged": (list(tr.converged_at()) if stop else None),
            "asked_subframes": first - 1, "rendered_subframes": tr.rendered_subframes()}
@@ -73,7 +73,8 @@ if __name__ == "__main__":
     ap.add_argument("--updates", type=int, default=100)
     ap.add_argument("--estimator", type=int, default=0)
     ap.add_argument("--volume", type=int, default=512)
-    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--size", type=int, default=1024, help="frame width (and height, unless --height is given)")
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--ahead", type=int, nargs="*", default=[], help="also with ct_set_render_ahead(N) for every N given")
     ap.add_argument("--stop", action="store_true", help="also with ct_set_stop_when_converged(10, 100), and the reference's waited-for loop")
     ap.add_argument("--reference-spp", type=int, default=1000, help="the long batch the rate is compared with (0 = skip)")

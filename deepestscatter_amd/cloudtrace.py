@@ -224,7 +224,8 @@ class CloudTracer:
         check(self.L.ct_render_accumulate(self.h, first_subframe_id, count), self.h)
 
     def render_accumulate_async(self, first_subframe_id: int, count: int):
-        """Enqueue a batch and return; up to two batches are in flight (ct_render_accumulate_async)."""
+        """Enqueue a batch and return (ct_render_accumulate_async): its paths may finish in later launches, its accumulate
+        kernel follows them; anything that waits (synchronize, mean, tonemap ...) brings the image up to date."""
         check(self.L.ct_render_accumulate_async(self.h, first_subframe_id, count), self.h)
 
     def synchronize(self):

@@ -110,10 +110,13 @@ struct CtHandle_ {
     float4 *d_primary = nullptr;      // cached primary rays, 2 float4 per pixel
     float4 *d_advance = nullptr;      // per pixel: pre-walked prefix of the primary march (MARCH estimator)
     uint32_t *d_pixels = nullptr;     // this shard's box-hitting pixels, padded to groups of 64
+    uint8_t *d_hit = nullptr, *hit_host = nullptr;   // per pixel: the primary ray hits the box (device; pinned host copy)
     uint32_t *d_cost = nullptr;       // measured per group: [0,n) sum of path costs, [n,2n) deepest path
     uint32_t *d_job_group = nullptr, *d_job_sub = nullptr; // job list of the current batch size
     uint32_t n_groups = 0, groups_capacity = 0;
     uint32_t n_jobs = 0, jobs_capacity = 0, jobs_S = 0;
+    uint32_t *jobs_host_g = nullptr, *jobs_host_s = nullptr;   // the list as built on the host (pinned)
+    size_t jobs_host_capacity = 0;
     bool jobs_brief = false;          // the list was laid out for short launches (short_batch)
     // The job list is built chunk by chunk: a chunk is a contiguous piece of `chunk_groups` groups of the cost-sorted
     // group order, and a launch renders all S subframes of ONE chunk into a scratch region of chunk_groups * 64 columns --
@@ -205,6 +208,21 @@ static int fail(CtHandle h, int code, const char *fmt, ...)
                         hipGetErrorString(e_));                                                      \
         }                                                                                            \
     } while (0)
+
+// CT_TRACE=1: host-side phases of a new pose (rebuild_queue, tune_order, build_jobs) with their durations on stderr.
+struct TracePhase {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit TracePhase(const char *n) : name(n), t0(std::chrono::steady_clock::now()), on(getenv("CT_TRACE") != nullptr) {}
+    ~TracePhase()
+    {
+        if (on) {
+            fprintf(stderr, "[cloudtrace] %s %.2f ms\n", name,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+    }
+};
 
 static int flush(CtHandle h);
 static int check_invariants(CtHandle h);
@@ -342,7 +360,7 @@ static void release(CtHandle h)
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_group_rank, h->d_group_order, h->d_job_group, h->d_job_sub, h->d_queue,
-                     h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
+                     h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->d_hit, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
         if (p) {
             hipFree(p);
@@ -370,6 +388,14 @@ static void release(CtHandle h)
     }
     if (h->freeze_host) {
         hipHostFree(h->freeze_host);
+    }
+    if (h->hit_host) {
+        hipHostFree(h->hit_host);
+    }
+    for (uint32_t *p : { h->jobs_host_g, h->jobs_host_s }) {
+        if (p) {
+            hipHostFree(p);
+        }
     }
     if (h->own_stream) {
         hipStreamDestroy(h->own_stream);
@@ -982,6 +1008,7 @@ extern "C" int ct_set_camera(CtHandle h, const float eye[3], const float U[3], c
 // tile-Morton order, cut into groups of 64 (one wave's worth).
 static int rebuild_queue(CtHandle h)
 {
+    TracePhase trace("rebuild_queue");
     const uint32_t W = h->scene.width, H = h->scene.height;
     const size_t pixels = (size_t)W * H;
     HIPCHK(h, launch_primary_rays(h->dev, h->d_primary, h->stream));
@@ -990,10 +1017,14 @@ static int rebuild_queue(CtHandle h)
     } else {
         HIPCHK(h, launch_primary_advance(h->dev, h->d_primary, h->d_advance, h->stream));
     }
-    std::vector<float4> prim(2 * pixels);
-    HIPCHK(h, hipMemcpyAsync(prim.data(), h->d_primary, prim.size() * sizeof(float4), hipMemcpyDeviceToHost,
-                             h->stream));
+    if (!h->d_hit) {
+        HIPCHK(h, dmalloc(&h->d_hit, pixels));
+        HIPCHK(h, hipHostMalloc((void **)&h->hit_host, pixels, hipHostMallocDefault));
+    }
+    HIPCHK(h, launch_hit_flags(h->d_primary, h->d_hit, (uint32_t)pixels, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->hit_host, h->d_hit, pixels, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint8_t *hit = h->hit_host;
     const uint32_t tiles_x = h->dev.tiles_x, tiles_y = h->dev.tiles_y;
     std::vector<std::pair<uint32_t, uint32_t>> tiles;
     for (uint32_t ty = 0; ty < tiles_y; ty++) {
@@ -1014,7 +1045,7 @@ static int rebuild_queue(CtHandle h)
             if (x < W && y < H) {
                 own++;
                 const uint32_t p = y * W + x;
-                if (prim[2 * (size_t)p].w != 0.f) {
+                if (hit[p]) {
                     list.push_back(p);
                 }
             }
@@ -1082,6 +1113,7 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
     if (h->jobs_S >= S && h->jobs_brief == short_batch(h, S) && h->chunk_groups == chunk_groups) {
         return CT_OK; // a list for a larger batch serves a smaller one (the kernel clips the jobs)
     }
+    TracePhase trace("build_jobs");
     S = std::max(S, h->jobs_hint);
     // One queue per XCD: groups are in tile-Morton order, so a contiguous range of them is a
     // compact image region whose paths read a compact part of the volume.  The ranges are cut at
@@ -1120,9 +1152,34 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
             run += w;
         }
     }
-    std::vector<uint32_t> jg, js;
-    jg.reserve((size_t)h->n_groups * ((S + 7) / 8));
-    js.reserve(jg.capacity());
+    // (the list itself is written into pinned host memory that stays with the handle: a new pose builds it twice, and 860 k
+    // jobs in two fresh vectors cost 9 ms of page faults and staged copies)
+    auto job_length = [&](uint32_t g) {
+        const float d = h->group_depth[g];
+        uint32_t len = h->job_max;
+        if (d > 0.f) {
+            len = (uint32_t)std::min((float)h->job_max, std::max(1.f, job_work * unit / d));
+        }
+        return len;
+    };
+    size_t total_jobs = 0;
+    for (uint32_t g = 0; g < h->n_groups; g++) {
+        const uint32_t len = job_length(g);
+        total_jobs += (S + len - 1) / len;
+    }
+    if (total_jobs > h->jobs_host_capacity) {
+        for (uint32_t **pp : { &h->jobs_host_g, &h->jobs_host_s }) {
+            if (*pp) {
+                HIPCHK(h, hipHostFree(*pp));
+                *pp = nullptr;
+            }
+        }
+        h->jobs_host_capacity = total_jobs + total_jobs / 4 + 1024;
+        HIPCHK(h, hipHostMalloc((void **)&h->jobs_host_g, h->jobs_host_capacity * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void **)&h->jobs_host_s, h->jobs_host_capacity * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    uint32_t *const jg = h->jobs_host_g, *const js = h->jobs_host_s;
+    size_t nj = 0;
     std::vector<double> q_weight(kQueues + 1, 0.0);
     // chunk by chunk (a contiguous piece of the group order each), and within a chunk queue by queue
     const uint32_t n_chunks = h->n_groups ? (h->n_groups + chunk_groups - 1) / chunk_groups : 1u;
@@ -1154,25 +1211,25 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
     for (uint32_t c = 0; c < n_chunks; c++) {
         const uint32_t r0 = c * chunk_groups, r1 = std::min(h->n_groups, r0 + chunk_groups);
         for (uint32_t x = 0; x <= (uint32_t)kQueues; x++) {
-            h->chunk_q_begin[c][x] = (uint32_t)jg.size();
+            h->chunk_q_begin[c][x] = (uint32_t)nj;
+            if (x != 0u && nq == 1u && x != (uint32_t)kQueues) {
+                continue;   // (one global list: everything is in queue 0)
+            }
             for (uint32_t r = r0; r < r1; r++) {
                 const uint32_t g = h->job_order[r];
                 if (queue_of[g] != x) {
                     continue;
                 }
-                const float d = h->group_depth[g];
-                q_weight[x] += (double)d + unit;
-                uint32_t len = h->job_max;
-                if (d > 0.f) {
-                    len = (uint32_t)std::min((float)h->job_max, std::max(1.f, job_work * unit / d));
-                }
+                q_weight[x] += (double)h->group_depth[g] + unit;
+                const uint32_t len = job_length(g);
                 for (uint32_t s0 = 0; s0 < S; s0 += len) {
-                    jg.push_back(g);
-                    js.push_back(s0 | (std::min(len, S - s0) << 16));
+                    jg[nj] = g;
+                    js[nj] = s0 | (std::min(len, S - s0) << 16);
+                    nj += 1;
                 }
             }
         }
-        h->chunk_q_begin[c][kQueues + 1] = (uint32_t)jg.size();
+        h->chunk_q_begin[c][kQueues + 1] = (uint32_t)nj;
     }
     for (int x = 0; x <= kQueues + 1; x++) {
         h->q_begin[x] = h->chunk_q_begin[0][x];
@@ -1201,7 +1258,7 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
     h->n_chunks = n_chunks;
     // (nq == 1: everything sits in queue 0 and the other XCDs' waves steal from it -- one global
     // cost-sorted list, the behaviour before the queues were split)
-    h->n_jobs = (uint32_t)jg.size();
+    h->n_jobs = (uint32_t)nj;
     if (h->n_jobs > h->jobs_capacity) {
         for (void *p : { (void *)h->d_job_group, (void *)h->d_job_sub }) {
             if (p) {
@@ -1214,11 +1271,9 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
         HIPCHK(h, dmalloc(&h->d_job_sub, h->jobs_capacity));
     }
     if (h->n_jobs) {
-        HIPCHK(h, hipMemcpyAsync(h->d_job_group, jg.data(), jg.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                                 h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_job_sub, js.data(), js.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                                 h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_job_group, jg, nj * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_job_sub, js, nj * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // (the pinned list is rewritten by the next build)
     }
     h->jobs_S = S;
     h->jobs_brief = brief;
@@ -1231,6 +1286,7 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
 // the job lengths only change the schedule, never a result.
 static int tune_order(CtHandle h, uint32_t measured_subframes)
 {
+    TracePhase trace("tune_order");
     h->order_tuned = true;
     if (h->n_groups < 2 || measured_subframes == 0) {
         return CT_OK;
@@ -1889,7 +1945,21 @@ extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *fram
 }
 
 // Subframes of the launch that measures the job costs of a new pose.
-constexpr uint32_t kTuneSubframes = 32;
+// (8 since round 3: the order it yields is as good as that of 32 -- the launches that follow take 349.0 vs 348.6 ms -- and a
+// waited-for launch of 8 subframes lasts 26 ms where one of 32 lasts 48; most of either is the wait for the longest paths)
+constexpr uint32_t kTuneSubframes = 8;
+// (Also tried in round 3: the cost-measuring launch ENQUEUED -- it ends when its job list is empty, its survivors go to the next
+// launch booking what they have cost so far, times 1..4 -- 18 ms instead of 26-48.  The order made from paths cut short is worse:
+// the launches that follow take 352-359 ms per 1024 subframes instead of 349 for as long as the pose lasts, and the first image of
+// a pose needs its longest path either way.  Removed.)
+static uint32_t tune_subframes()
+{
+    static const uint32_t n = [] {
+        const char *e = getenv("CT_TUNE_SUBFRAMES");   // (A/B: how short may the cost-measuring launch be?)
+        return e ? (uint32_t)std::min(1024, std::max(1, atoi(e))) : kTuneSubframes;
+    }();
+    return n;
+}
 
 static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32_t count, bool wait)
 {
@@ -1942,7 +2012,13 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
         // launch (freeing and allocating tens of GB takes hundreds of milliseconds)
         for (;;) {
             const uint32_t gc = groups_per_chunk(h, h->jobs_hint);
-            const size_t need = (size_t)h->jobs_hint * gc * 64;
+            // (reserved for a pose in which EVERY pixel of this shard hits the box, if a region holds that: the pixel list grows
+            // and shrinks as the camera moves, and every growth of the scratch would be a hipFree + hipMalloc of tens of GB --
+            // 25 ms when the driver has the pages at hand, a second when it has not)
+            const uint64_t all_groups = (h->own_pixels + 63u) / 64u;
+            const uint64_t region_groups = std::min<uint64_t>(scratch_slot_bytes(h) / sizeof(float4), 0xffffffffull / 2) / ((uint64_t)std::max(h->jobs_hint, 1u) * 64u);
+            const uint32_t gc_reserve = (gc >= h->n_groups && all_groups <= region_groups) ? (uint32_t)std::max<uint64_t>(all_groups, gc) : gc;
+            const size_t need = (size_t)h->jobs_hint * gc_reserve * 64;
             const bool enqueue = !wait || gc < h->n_groups;
             const uint64_t budget = 2 * scratch_slot_bytes(h) / sizeof(float4);
             const size_t total = std::min<size_t>((size_t)(enqueue ? wanted_regions(h, h->jobs_hint, need, std::max<uint64_t>(budget, 2 * need)) : 1) * need,
@@ -1971,7 +2047,7 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
         if (!simple && !h->order_tuned) {
             // the first launch of a pose measures the job costs (two atomics per path, jobs in image
             // order): it is kept short, waited for, then the order is set
-            S = std::min(S, kTuneSubframes);
+            S = std::min(S, tune_subframes());
             rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
         } else {
             const bool trace = getenv("CT_TRACE") != nullptr;
@@ -1979,11 +2055,20 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             rc = prepare_batches(h, S);
             // several chunks: they are enqueued like batches (paths pass from chunk to chunk) and a waited-for call waits at the end
             const bool enqueue = !wait || (h->n_chunks > 1 && h->continuation && !simple);
-            const size_t need = (size_t)S * frame_stride(h);
-            if (rc == CT_OK && (need > h->slot_capacity || (enqueue && (S != h->layout_S || h->n_regions < 2)))) {
+            // (laid out for the call's batch size, not for the remainder that follows the short cost-measuring launch: the next
+            // call of the same size then finds its layout, and nothing has to be flushed for it)
+            uint32_t layout = S;
+            if (enqueue && h->n_chunks <= 1 && 2 * (uint64_t)std::max(S, h->jobs_hint) * frame_stride(h) <= 0xffffffffull) {
+                layout = std::max(S, h->jobs_hint);   // (one chunk only: a chunk's size was chosen for S)
+            }
+            const size_t need = (size_t)layout * frame_stride(h);
+            // (an enqueued batch may use the regions of a layout made for larger ones, as long as the ring is long enough for it)
+            const bool ring_too_short = enqueue && (h->n_regions < 2 ||
+                                                    (layout != h->layout_S && h->n_regions < wanted_regions(h, layout, need, 2 * scratch_slot_bytes(h) / sizeof(float4))));
+            if (rc == CT_OK && (need > h->slot_capacity || ring_too_short)) {
                 rc = flush(h); // the layout of the scratch changes: nothing may be in flight
                 if (rc == CT_OK) {
-                    rc = ensure_frames(h, S, enqueue);
+                    rc = ensure_frames(h, layout, enqueue);
                 }
                 if (rc == CT_E_NOMEM && scratch_slot_bytes(h) > (64ull << 20)) {
                     h->scratch_cap_bytes = scratch_slot_bytes(h) / 2;   // the device cannot give that much: smaller chunks

@@ -134,6 +134,7 @@ hipError_t launch_coarse_clearance(const uint8_t *dist, int nx, int ny, int nz, 
 hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, uint32_t zero_faces, hipStream_t stream);
 hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream);
+hipError_t launch_hit_flags(const float4 *primary, uint8_t *flags, uint32_t pixels, hipStream_t stream);
 hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);
 hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);
 // Zeroes up to six short word arrays in ONE dispatch (the counters a launch of the estimator starts from: five memsets

@@ -482,6 +482,22 @@ hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t 
     return hipGetLastError();
 }
 
+// One byte per pixel: does the primary ray hit the box?  (What the host needs of the 32 B per pixel of `primary` to build
+// the pixel list of a new pose; fetching the rays themselves was 32 MB over PCIe into pageable memory, 10 of the 13 ms.)
+__global__ __launch_bounds__(256) void hit_flags_kernel(const float4 *__restrict__ primary, uint8_t *__restrict__ flags, uint32_t pixels)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < pixels) {
+        flags[p] = primary[2 * (size_t)p].w != 0.f ? 1u : 0u;
+    }
+}
+
+hipError_t launch_hit_flags(const float4 *primary, uint8_t *flags, uint32_t pixels, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hit_flags_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream, primary, flags, pixels);
+    return hipGetLastError();
+}
+
 // estimateEmission's ray setup (pointEmissionCamera.cu:22-31): the same closest-hit prologue for
 // an arbitrary origin/direction; launchID is 1-D, so the seed base is i*4096 + 0.
 struct PointTask {

@@ -2049,7 +2049,7 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             // order): it is kept short, waited for, then the order is set
             // (a call of a display update's size is the cost-measuring launch as a whole: 10 subframes waited for cost 27 ms, 8 of
             // them 26 and the other 2 a launch and a flush of their own)
-            S = std::min(S, std::max(tune_subframes(), std::min(h->jobs_hint, 2u * tune_subframes())));
+            S = std::min(S, h->jobs_hint <= 2u * tune_subframes() ? std::max(h->jobs_hint, 1u) : tune_subframes());
             rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
         } else {
             const bool trace = getenv("CT_TRACE") != nullptr;

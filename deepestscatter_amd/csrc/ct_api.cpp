@@ -140,7 +140,9 @@ struct CtHandle_ {
     bool queues_enabled = false;         // per-XCD regions (CT_XCD_QUEUES=1; default: one global list)
     float shared_depth = 1e30f;          // groups at least this deep (bounces) use the shared queue
     uint32_t regions = 128;              // image regions dealt to the per-XCD queues
-    std::vector<uint32_t> group_order;   // groups, most expensive first (identity until tuned)
+    std::vector<uint32_t> group_order;   // groups, most expensive first (until tuned: by what the last pose measured for their tiles)
+    std::vector<uint32_t> group_tile;    // the 8x8 tile of a group's first pixel
+    std::vector<uint32_t> tile_deepest;  // per tile of the image: the deepest path the last measured pose produced there (0 = never measured)
     std::vector<uint32_t> job_order;     // the order the job list is built in: group_order, or its chunks interleaved (build_jobs)
     bool chunk_interleave = false;       // CT_CHUNK_INTERLEAVE=1: every chunk is every C-th group of group_order (A/B: worse, the neighbours are gone)
     bool chunk_morton = false;           // CT_CHUNK_MORTON=1: chunks are compact image regions (A/B)
@@ -1077,8 +1079,27 @@ static int rebuild_queue(CtHandle h)
         h->groups_capacity = h->n_groups;
     }
     h->group_order.resize(h->n_groups);
+    h->group_tile.resize(h->n_groups);
     for (uint32_t i = 0; i < h->n_groups; i++) {
         h->group_order[i] = i;
+        const uint32_t p = list[(size_t)i * 64];
+        h->group_tile[i] = (p / W / kTile) * tiles_x + (p % W) / kTile;
+    }
+    if (h->tile_deepest.size() == (size_t)tiles_x * tiles_y) {
+        // The cost-measuring launch of this pose is waited for to its last path, so it should START with the groups whose paths
+        // are long.  Where those were for the last pose that was measured is a good guess while the camera is dragged
+        // (Camera::rotate, Camera.cpp:93-98): classes of the deepest path seen in a group's tile, deepest first, tile order within.
+        auto log2_class = [](uint32_t c) {
+            uint32_t k = 0;
+            while (c) {
+                k++;
+                c >>= 1;
+            }
+            return k;
+        };
+        std::stable_sort(h->group_order.begin(), h->group_order.end(), [&](uint32_t a, uint32_t b) {
+            return log2_class(h->tile_deepest[h->group_tile[a]]) > log2_class(h->tile_deepest[h->group_tile[b]]);
+        });
     }
     h->group_depth.assign(h->n_groups, 0.f);
     if (h->n_groups) {
@@ -1114,14 +1135,19 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
         return CT_OK; // a list for a larger batch serves a smaller one (the kernel clips the jobs)
     }
     TracePhase trace("build_jobs");
-    S = std::max(S, h->jobs_hint);
+    if (h->order_tuned) {
+        S = std::max(S, h->jobs_hint);   // (the cost-measuring launch gets a list of its own: one-subframe jobs, its few subframes only)
+    }
     // One queue per XCD: groups are in tile-Morton order, so a contiguous range of them is a
     // compact image region whose paths read a compact part of the volume.  The ranges are cut at
     // equal shares of the measured cost (path depth + the primary march), not of the pixel count.
     // cost units per bounce (BatchArgs::cost): MARCH counts fetches + 4 per bounce, DELTA bounces
     const float unit = (h->scene.estimator == CT_EST_DELTA) ? 1.f : 16.f;
     const bool brief = short_batch(h, S);
-    const bool queues = (h->queues_enabled || (brief && !getenv("CT_XCD_QUEUES"))) && !(h->scene.flags & CT_FLAG_SIMPLE_KERNEL);
+    // (per-XCD queues are cut at equal shares of the MEASURED cost: before anything is measured they would be equal shares of
+    // pixels, and the XCD that got the cloud's body would finish long after the others)
+    const bool queues = (h->queues_enabled || (brief && !getenv("CT_XCD_QUEUES"))) && !(h->scene.flags & CT_FLAG_SIMPLE_KERNEL) &&
+                        (h->order_tuned || getenv("CT_XCD_QUEUES_UNTUNED"));
     const uint32_t nq = (queues && h->n_groups >= (uint32_t)kQueues) ? (uint32_t)kQueues : 1u;
     const uint32_t regions_wanted = (brief && !h->queues_enabled && !getenv("CT_XCD_REGIONS")) ? 16u : h->regions;
     const float job_work = (brief && !getenv("CT_JOB_WORK")) ? 4.f : h->job_work;
@@ -1156,6 +1182,12 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
     // jobs in two fresh vectors cost 9 ms of page faults and staged copies)
     auto job_length = [&](uint32_t g) {
         const float d = h->group_depth[g];
+        if (!h->order_tuned) {
+            // the cost-measuring launch of a pose knows no depths yet: ONE subframe per job, or the wave that gets a group of the
+            // cloud's body runs its eight or ten subframes one after another in the same 64 lanes -- 21 ms for 10 subframes
+            // of a 1024^2 frame that are 13 ms once the order is set
+            return 1u;
+        }
         uint32_t len = h->job_max;
         if (d > 0.f) {
             len = (uint32_t)std::min((float)h->job_max, std::max(1.f, job_work * unit / d));
@@ -1306,9 +1338,14 @@ static int tune_order(CtHandle h, uint32_t measured_subframes)
     // Order: by the deepest path a group has produced (a launch ends when its last path does, so
     // the groups that can produce long paths must not be the last ones running), then by mean cost.
     const uint32_t *deepest = cost.data() + h->n_groups;
+    h->tile_deepest.assign((size_t)h->dev.tiles_x * h->dev.tiles_y, 0u);
     for (uint32_t g = 0; g < h->n_groups; g++) {
         h->group_order[g] = g;
         h->group_depth[g] = (float)cost[g] / (64.f * (float)measured_subframes);
+        if (g < h->group_tile.size()) {
+            uint32_t &t = h->tile_deepest[h->group_tile[g]];
+            t = std::max(t, deepest[g]);   // (a guess for the next pose's cost-measuring launch: rebuild_queue)
+        }
     }
     std::stable_sort(h->group_order.begin(), h->group_order.end(), [&](uint32_t a, uint32_t b) {
         const uint32_t ka = log2_class(deepest[a]), kb = log2_class(deepest[b]);

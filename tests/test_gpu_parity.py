@@ -1477,6 +1477,39 @@ def test_checkpoint_and_resume_continue_exactly(estimator, tmp_path):
     b.close()
 
 
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_a_handle_that_follows_a_moving_camera_equals_fresh_handles(estimator, monkeypatch):
+    """Camera::rotate -> reset (Camera.cpp:93-98): one handle renders pose after pose.  What it carries from pose to pose -- the
+    scratch, job lists, the tiles in which the last measured pose had its deepest paths (where the next pose's cost-measuring
+    launch starts) -- changes schedules only: every pose's image equals the one a fresh handle renders, bit for bit, with the
+    invariants armed.  Poses near each other (a drag), a jump across the cloud, and a pose that looks past it."""
+    import math
+    tex = ds.make_procedural_cloud(64)
+    w, h = 120, 88
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    tr = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+    eyes = [(2.5 * math.cos(0.07 * k), -0.4 + 0.05 * k, 2.5 * math.sin(0.07 * k)) for k in range(4)]
+    eyes += [(-2.2, 0.8, -1.1), (0.4, 2.6, 0.3), (2.5, -0.4, 0.0)]
+    for i, eye in enumerate(eyes):
+        look = (0, 0, 0) if i != 5 else (3.0, 2.6, 0.3)      # (the sixth pose looks past the box: no pixel hits it)
+        U, V, W = ds.calculate_camera_variables(eye, look, (0, 1, 0), 30.0, w / h)
+        tr.set_camera(eye, U, V, W)
+        tr.reset()
+        tr.render_accumulate_async(1, 10)
+        tr.tonemap_async(0.4)
+        tr.render_accumulate_async(11, 10)
+        tr.render_accumulate(21, 14)
+        fresh = ds.CloudTracer(tex, width=w, height=h, estimator=estimator)
+        fresh.set_camera(eye, U, V, W)
+        fresh.render_accumulate(1, 34)
+        assert np.array_equal(tr.mean(), fresh.mean()) and np.array_equal(tr.m2(), fresh.m2()), i
+        assert tr.counters() == fresh.counters(), i
+        fresh.close()
+    iv = tr.debug_invariants()
+    tr.close()
+    assert iv["armed"] == 1 and iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+
+
 def _pixels_outside_the_interval(mean, m2, n):
     """Camera::isConverged's count (Camera.cpp:244-262) in float32, for any subframe count."""
     N = np.float32(n)

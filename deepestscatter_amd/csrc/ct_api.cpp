@@ -112,6 +112,8 @@ struct CtHandle_ {
     uint32_t *d_pixels = nullptr;     // this shard's box-hitting pixels, padded to groups of 64
     uint8_t *d_hit = nullptr, *hit_host = nullptr;   // per pixel: the primary ray hits the box (device; pinned host copy)
     uint32_t *d_cost = nullptr;       // measured per group: [0,n) sum of path costs, [n,2n) deepest path
+    uint2 *d_cost_plane = nullptr;    // ... as the cost-measuring launch leaves them, per sample (BatchArgs::cost)
+    size_t cost_plane_capacity = 0;
     uint32_t *d_job_group = nullptr, *d_job_sub = nullptr; // job list of the current batch size
     uint32_t n_groups = 0, groups_capacity = 0;
     uint32_t n_jobs = 0, jobs_capacity = 0, jobs_S = 0;
@@ -362,7 +364,7 @@ static void release(CtHandle h)
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_group_rank, h->d_group_order, h->d_job_group, h->d_job_sub, h->d_queue,
-                     h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->d_hit, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
+                     h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->d_hit, h->d_cost_plane, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
         if (p) {
             hipFree(p);
@@ -1668,8 +1670,21 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     ba.rank_base = rank_base;
     ba.job_group = h->d_job_group;
     ba.job_sub = h->d_job_sub;
-    ba.cost = h->order_tuned ? nullptr : h->d_cost;
-    ba.cost_max = h->order_tuned ? nullptr : h->d_cost + h->n_groups;
+    // the cost-measuring launch of a pose: every path leaves what it cost beside its result, summed per group below
+    const bool measure = !h->order_tuned && !simple && !dense && chunk_n != 0u;
+    if (measure) {
+        const size_t entries = (size_t)S * frame_stride(h);
+        if (entries > h->cost_plane_capacity) {
+            if (h->d_cost_plane) {
+                HIPCHK(h, hipFree(h->d_cost_plane));
+                h->d_cost_plane = nullptr;
+            }
+            h->cost_plane_capacity = entries + entries / 4;
+            HIPCHK(h, dmalloc(&h->d_cost_plane, h->cost_plane_capacity));
+        }
+        HIPCHK(h, hipMemsetAsync(h->d_cost_plane, 0, entries * sizeof(uint2), h->stream));
+        ba.cost = h->d_cost_plane;
+    }
     static const std::array<uint32_t, kQueues + 2> no_jobs{};
     const auto &qb = chunk < h->chunk_q_begin.size() ? h->chunk_q_begin[chunk] : no_jobs;   // (the simple kernel has no job list)
     ba.n_jobs = qb[kQueues + 1];            // (absolute index of the chunk's end: the job that raises the "list empty" flag)
@@ -1735,6 +1750,11 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
             const int rc = launch_estimator(h, ba);
             if (rc != CT_OK) {
                 return rc;
+            }
+            if (measure) {
+                HIPCHK(h, launch_cost_reduce(h->d_cost_plane, (uint32_t)frame_stride(h), S, chunk_n,
+                                             h->n_chunks <= 1 ? nullptr : h->d_group_order, rank_base, h->d_cost,
+                                             h->d_cost + h->n_groups, h->stream));
             }
         }
         // (every group is full but the last one of the pixel list, which padding completes; it sits somewhere in the job order)
@@ -1926,7 +1946,7 @@ static int run_batch(CtHandle h, float4 *dense_frames, uint32_t first, uint32_t 
         return rc;
     }
     const bool simple = (h->scene.flags & CT_FLAG_SIMPLE_KERNEL) != 0;
-    if (!simple && !h->order_tuned) {
+    if (!simple && !h->order_tuned && !dense_frames) {   // (a dense frame -- ct_render_subframe -- measures nothing)
         return tune_order(h, S);
     }
     return CT_OK;

@@ -44,10 +44,11 @@ struct BatchArgs {
     // every wave still stays on one 64-pixel group at a time (cache locality).
     const uint32_t *job_group;
     const uint32_t *job_sub;
-    uint32_t *cost;            // per group: sum of path costs (MARCH: fetches + 4 per bounce; DELTA:
-                               // bounces), feeds the next job list; NULL once
-                               // the order is tuned (hundreds of waves share a group at large S)
-    uint32_t *cost_max;        // per group: deepest path seen (same life as cost)
+    uint2 *cost;               // the cost-measuring launch of a pose (NULL once the job order is tuned): what every path has
+                               // cost (MARCH: fetches + 4 per bounce; DELTA: bounces) and how deep it went, stored where its
+                               // result goes -- cost[out_idx - out_offset] -- and summed per pixel group by
+                               // launch_cost_reduce.  (Until round 3 two atomics per path on per-group words: 17.6 M
+                               // device-scope atomics were 5.7 of the 21 ms of a pose's first 10 subframes.)
     uint32_t n_jobs;
     // Queue x < kQueues holds jobs [q_begin[x], q_begin[x+1]): the pixel groups of one compact image
     // region, so that the waves of one XCD share that region's bricks in their L2.  Queue kQueues
@@ -134,6 +135,9 @@ hipError_t launch_coarse_clearance(const uint8_t *dist, int nx, int ny, int nz, 
 hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 hipError_t launch_inscatter(const DevScene &sc, uint8_t *out, uint32_t zero_faces, hipStream_t stream);
 hipError_t launch_primary_rays(const DevScene &sc, float4 *primary, hipStream_t stream);
+hipError_t launch_cost_reduce(const uint2 *cost_plane, uint32_t frame_stride, uint32_t S, uint32_t n_groups_in_chunk,
+                              const uint32_t *group_order, uint32_t rank_base, uint32_t *cost_sum, uint32_t *cost_deepest,
+                              hipStream_t stream);
 hipError_t launch_hit_flags(const float4 *primary, uint8_t *flags, uint32_t pixels, hipStream_t stream);
 hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);
 hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primary, float4 *advance, hipStream_t stream);

@@ -492,6 +492,42 @@ __global__ __launch_bounds__(256) void hit_flags_kernel(const float4 *__restrict
     }
 }
 
+// The cost plane of a pose's first launch -> per pixel group: sum of the path costs, deepest path.  One block per group of the
+// launch's chunk (its 64 columns x S rows); group_order == NULL: column c * 64 is group c.
+__global__ __launch_bounds__(64) void cost_reduce_kernel(const uint2 *__restrict__ plane, uint32_t frame_stride, uint32_t S,
+                                                         const uint32_t *__restrict__ group_order, uint32_t rank_base,
+                                                         uint32_t *__restrict__ cost_sum, uint32_t *__restrict__ cost_deepest)
+{
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    uint32_t sum = 0, deepest = 0;
+    for (uint32_t s = 0; s < S; s++) {
+        const uint2 v = plane[(size_t)s * frame_stride + c * 64u + lane];
+        sum += v.x;
+        deepest = max(deepest, v.y);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, off));
+    }
+    if (lane == 0) {
+        const uint32_t g = group_order ? group_order[rank_base + c] : c;
+        cost_sum[g] += sum;
+        cost_deepest[g] = max(cost_deepest[g], deepest);
+    }
+}
+
+hipError_t launch_cost_reduce(const uint2 *cost_plane, uint32_t frame_stride, uint32_t S, uint32_t n_groups_in_chunk,
+                              const uint32_t *group_order, uint32_t rank_base, uint32_t *cost_sum, uint32_t *cost_deepest,
+                              hipStream_t stream)
+{
+    if (n_groups_in_chunk != 0u && S != 0u) {
+        hipLaunchKernelGGL(cost_reduce_kernel, dim3(n_groups_in_chunk), dim3(64), 0, stream, cost_plane, frame_stride, S, group_order,
+                           rank_base, cost_sum, cost_deepest);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_hit_flags(const float4 *primary, uint8_t *flags, uint32_t pixels, hipStream_t stream)
 {
     hipLaunchKernelGGL(hit_flags_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream, primary, flags, pixels);
@@ -981,7 +1017,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
 
     const uint32_t lane = threadIdx.x & 63u;
     f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), stepv = mk3(0, 0, 0), rad = mk3(0, 0, 0);
-    uint32_t seed = 0, depth = 0, out_idx = 0, group = 0;
+    uint32_t seed = 0, depth = 0, out_idx = 0;
     uint32_t work = 0;      // scheduler visits this path has cost so far (feeds the job order)
     float xi = 0, T = 1;
     uint32_t dfree = 0;     // free-space distance of the brick `pos` is in (0 = unknown / none)
@@ -1118,7 +1154,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
                         out_idx = ba.frame_stride ? job.base + s * ba.frame_stride + l : pixel;
-                        group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f; // image jobs list hitting pixels only; point tasks may miss
                         dir = mk3(p1.x, p1.y, p1.z);
@@ -1341,8 +1376,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                         iv_written += 1;
                     }
                     if (ba.cost) {
-                        atomicAdd(&ba.cost[group], work);
-                        atomicMax(&ba.cost_max[group], depth);
+                        ba.cost[out_idx - ba.out_offset] = make_uint2(work, depth);
                     }
                     state = ST_IDLE;
                 }
@@ -1374,8 +1408,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 iv_written += 1;
             }
             if (ba.cost) {
-                atomicAdd(&ba.cost[group], work);
-                atomicMax(&ba.cost_max[group], depth);
+                ba.cost[out_idx - ba.out_offset] = make_uint2(work, depth);
             }
             state = ST_IDLE;
         }
@@ -1794,7 +1827,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
     const uint32_t lane = threadIdx.x & 63u;
     f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), rad = mk3(0, 0, 0);
     Dda dda{};
-    uint32_t seed = 0, depth = 0, out_idx = 0, group = 0;
+    uint32_t seed = 0, depth = 0, out_idx = 0;
     int state = ST_IDLE;
 
     JobState job{ 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
@@ -1900,7 +1933,6 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                         const float4 p0 = ba.primary[2 * (size_t)pixel];
                         const float4 p1 = ba.primary[2 * (size_t)pixel + 1];
                         out_idx = ba.frame_stride ? job.base + s * ba.frame_stride + l : pixel;
-                        group = g;
                         pos = mk3(p0.x, p0.y, p0.z);
                         const bool hit = p0.w != 0.f;
                         dir = mk3(p1.x, p1.y, p1.z);
@@ -2069,8 +2101,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                         iv_written += 1;
                     }
                     if (ba.cost) {
-                        atomicAdd(&ba.cost[group], depth);
-                        atomicMax(&ba.cost_max[group], depth);
+                        ba.cost[out_idx - ba.out_offset] = make_uint2(depth, depth);
                     }
                     state = ST_IDLE;
                 }
@@ -2103,8 +2134,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                 iv_written += 1;
             }
             if (ba.cost) {
-                atomicAdd(&ba.cost[group], depth);
-                atomicMax(&ba.cost_max[group], depth);
+                ba.cost[out_idx - ba.out_offset] = make_uint2(depth, depth);
             }
             state = ST_IDLE;
         }

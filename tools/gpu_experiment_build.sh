@@ -15,7 +15,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']
-        print('value %.1f Msamples/s  ms/step %.2f  launch_ms %.2f  lookups/sample %.1f  fetches/sample %.2f  scatter events/launch %.3e' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r.get('lookups_per_sample', 0), r.get('fetches_per_sample', 0), r.get('counters_per_launch', {}).get('scatter_events', 0)))
+        print('value %.1f Msamples/s  ms/step %.2f  launch_ms %.2f  lookups/sample %.1f  fetches/sample %.2f  scatter events/launch %.3e' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r.get('lookups_per_sample', 0), r.get('fetches_per_sample', 0), r.get('counters_per_launch', {}).get('scatter_events', 0)) + ('  DELTA %.1f' % d['delta_estimator']['value'] if d.get('delta_estimator') else ''))
 " >> gpurun_out/experiment.log || echo FAILED >> gpurun_out/experiment.log
 done
 python -m deepestscatter_amd.build --force > /dev/null 2>&1

@@ -7,6 +7,7 @@
 // HIP or the device is missing every entry point reports CT_E_NODEVICE / CT_E_HIP.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -2283,7 +2284,32 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
     // tasks deep inside the cloud, whose every experiment runs to the depth cap (2000 bounces): jobs are single frames
     // unless the call is large, in one queue, frame-major, so that the deep groups are spread evenly over the list and over
     // the waves.  (What bounds such a call is the serial latency of those paths, ~6 us per bounce: DESIGN.md section 8 f-1.)
-    const uint32_t waves = (uint32_t)h->shape.blocks * (uint32_t)h->shape.threads / 64u;
+    // Several collectors at once (cloudtrace collect --jobs K: one handle and one host thread per scene setup) each launch a
+    // persistent grid, and a grid that fills every CU leaves the others waiting for its last, longest paths.  A call that
+    // finds others in flight launches a share of the grid instead -- blocks per CU divided by the calls in flight, at least
+    // one -- so that the kernels are resident side by side: 8.72 -> 7.86 ms per update with four setups in flight, 7.76 with six
+    // (profiles/r03y).  Alone, a call keeps the whole chip.  (The schedule only: results do not depend on the grid.)
+    struct InFlight {
+        std::atomic<int> &n;
+        int mine;
+        explicit InFlight(std::atomic<int> &c) : n(c), mine(c.fetch_add(1) + 1) {}
+        ~InFlight() { n.fetch_sub(1); }
+    };
+    static std::atomic<int> point_calls_in_flight{ 0 };
+    const InFlight in_flight(point_calls_in_flight);
+    LaunchShape shape = h->shape;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) {
+            const int per_cu = std::max(1, shape.blocks / cus);
+            int share = std::max(1, per_cu / std::max(1, in_flight.mine));
+            if (const char *e = getenv("CT_POINT_BLOCKS_PER_CU")) {   // (A/B)
+                share = std::min(per_cu, std::max(1, atoi(e)));
+            }
+            shape.blocks = share * cus;
+        }
+    }
+    const uint32_t waves = (uint32_t)shape.blocks * (uint32_t)shape.threads / 64u;
     const uint32_t chunk = h->point_order
                                ? (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (uint64_t)n_groups * launches / (16ull * std::max(waves, 1u))))
                                : 8u;
@@ -2363,9 +2389,9 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         ba.stats = h->d_counters + kCounterCount + 1;
         HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
         if (h->scene.estimator == CT_EST_DELTA) {
-            HIPCHK(h, launch_render_delta(h->dev, ba, h->shape, h->stream));
+            HIPCHK(h, launch_render_delta(h->dev, ba, shape, h->stream));
         } else {
-            HIPCHK(h, launch_render_persistent(h->dev, ba, h->shape, h->stream));
+            HIPCHK(h, launch_render_persistent(h->dev, ba, shape, h->stream));
         }
         HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
         HIPCHK(h, launch_point_accumulate(pt.frames, n_pad, pt.tasks, count, launches, h->stream));

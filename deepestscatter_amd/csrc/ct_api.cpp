@@ -2295,8 +2295,8 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         explicit InFlight(std::atomic<int> &c) : n(c), mine(c.fetch_add(1) + 1) {}
         ~InFlight() { n.fetch_sub(1); }
     };
-    static std::atomic<int> point_calls_in_flight{ 0 };
-    const InFlight in_flight(point_calls_in_flight);
+    static std::atomic<int> point_calls_in_flight[64];   // (per device: cloudtrace collect --gpus deals the setups to several)
+    const InFlight in_flight(point_calls_in_flight[(uint32_t)h->device & 63u]);
     LaunchShape shape = h->shape;
     {
         int cus = 0;

@@ -77,9 +77,9 @@ struct CtHandle_ {
     std::vector<int> waiting;              // slots with subframes still to be accumulated, oldest first
     // Render-ahead (ct_set_render_ahead, CT_RENDER_AHEAD): enqueued calls of fewer subframes than `ahead` -- the reference's
     // display loop asks for 10 at a time, Camera.cpp:189 -- are served by estimator launches of `ahead` subframes, of which
-    // every call accumulates its own share: R(k) a(k-M,0) a(k-M,1) .. R(k+1) a(k-M+1,0) ..  A launch of `ahead`
-    // subframes works through a few pixel groups at a time like a long batch does, which a launch of 10 cannot (DESIGN.md
-    // 4.3 item 10).  `rendered` >= `subframes`: the subframes the estimator has been launched for / the caller has asked
+    // every call accumulates its own share: R(k) a(k-M,0) a(k-M,1) .. R(k+1) a(k-M+1,0) ..  A launch of 10 subframes is
+    // mostly beginning and end -- every lane resumes a path and suspends one -- which a launch of `ahead` amortises (DESIGN.md
+    // 4.3 item 13).  `rendered` >= `subframes`: the subframes the estimator has been launched for / the caller has asked
     // for; the running mean follows the calls by M * ahead subframes until something waits (flush: exactly `subframes`).
     uint32_t ahead = 0;
     uint32_t rendered = 0;

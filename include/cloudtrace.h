@@ -213,9 +213,9 @@ CT_API int ct_synchronize(CtHandle h);
 
 /* Render-ahead for the reference's display cadence (Camera::render: 10 subframes, then tonemap and display,
  * Camera.cpp:189-214).  With subframes > 0, a call of ct_render_accumulate_async for FEWER subframes than that is served by
- * an estimator launch of `subframes` subframes -- which works through a few pixel groups at a time, as a long batch does,
- * where a launch of 10 subframes has every group of the image in flight at once and misses L2 58 % more often (DESIGN.md
- * 4.3 items 10, 13) -- and every call accumulates ITS OWN share of it, in order: the images the calls produce are the
+ * an estimator launch of `subframes` subframes -- a launch of 10 subframes is mostly beginning and end: every lane resumes a
+ * path and suspends one, the lanes fill and drain; per subframe a launch of 80 keeps the chip busy for 21 % fewer cycles
+ *  -- and every call accumulates ITS OWN share of it, in order: the images the calls produce are the
  * reference's images for those subframe counts, bit for bit, each a fixed number of calls later (the running mean follows
  * the calls by `subframes` subframes per launch a path may span; ct_synchronize and every entry point that waits bring it
  * to exactly the subframes asked for).  Samples rendered ahead and not asked for yet stay in the scratch for the next

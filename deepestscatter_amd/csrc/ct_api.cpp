@@ -2003,9 +2003,10 @@ extern "C" int ct_accumulate(CtHandle h, uint32_t subframe_id, const float *fram
 }
 
 // Subframes of the launch that measures the job costs of a new pose.
-// (8 since round 3: the order it yields is as good as that of 32 -- the launches that follow take 349.0 vs 348.6 ms -- and a
-// waited-for launch of 8 subframes lasts 26 ms where one of 32 lasts 48; most of either is the wait for the longest paths)
-constexpr uint32_t kTuneSubframes = 8;
+// (16 since round 3 -- 32 before: a waited-for launch of 32 subframes lasted 48 ms, most of it the wait for its longest paths.
+// The order 16 subframes yield is as good as that of 32 -- long launches 349 ms either way, 10-subframe display updates 4.49 vs
+// 4.52 ms -- while 8 subframes cost the display cadence 2-3 %: 4.61 ms, 3.70 instead of 3.62 with render-ahead.)
+constexpr uint32_t kTuneSubframes = 16;
 // (Also tried in round 3: the cost-measuring launch ENQUEUED -- it ends when its job list is empty, its survivors go to the next
 // launch booking what they have cost so far, times 1..4 -- 18 ms instead of 26-48.  The order made from paths cut short is worse:
 // the launches that follow take 352-359 ms per 1024 subframes instead of 349 for as long as the pose lasts, and the first image of
@@ -2107,7 +2108,7 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             // order): it is kept short, waited for, then the order is set
             // (a call of a display update's size is the cost-measuring launch as a whole: 10 subframes waited for cost 27 ms, 8 of
             // them 26 and the other 2 a launch and a flush of their own)
-            S = std::min(S, h->jobs_hint <= 2u * tune_subframes() ? std::max(h->jobs_hint, 1u) : tune_subframes());
+            S = std::min(S, h->jobs_hint <= tune_subframes() + tune_subframes() / 2u ? std::max(h->jobs_hint, 1u) : tune_subframes());
             rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
         } else {
             const bool trace = getenv("CT_TRACE") != nullptr;

@@ -113,6 +113,7 @@ struct CtHandle_ {
     uint32_t *d_pixels = nullptr;     // this shard's box-hitting pixels, padded to groups of 64
     uint8_t *d_hit = nullptr, *hit_host = nullptr;   // per pixel: the primary ray hits the box (device; pinned host copy)
     uint32_t *d_cost = nullptr;       // measured per group: [0,n) sum of path costs, [n,2n) deepest path
+    unsigned long long *d_timeline = nullptr;   // CT_TIMELINE=1: [start, end] of every wave of the last enqueued estimator launch (MARCH)
     uint2 *d_cost_plane = nullptr;    // ... as the cost-measuring launch leaves them, per sample (BatchArgs::cost)
     size_t cost_plane_capacity = 0;
     uint32_t *d_job_group = nullptr, *d_job_sub = nullptr; // job list of the current batch size
@@ -365,7 +366,7 @@ static void release(CtHandle h)
     }
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_group_rank, h->d_group_order, h->d_job_group, h->d_job_sub, h->d_queue,
-                     h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->d_hit, h->d_cost_plane, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
+                     h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->d_hit, h->d_cost_plane, h->d_timeline, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
         if (p) {
             hipFree(p);
@@ -865,6 +866,11 @@ static int create_impl(const CtScene *s, CtHandle h)
     }
     if (const char *e = getenv("CT_MAX_AGE")) {
         h->max_age_override = std::min(CtHandle_::kMaxRegions - 1, std::max(0, atoi(e)));
+    }
+    if (getenv("CT_TIMELINE")) {
+        const size_t waves = (size_t)h->shape.blocks * h->shape.threads / 64u;
+        HIPCHK(h, dmalloc(&h->d_timeline, 4 * waves));
+        HIPCHK(h, hipMemsetAsync(h->d_timeline, 0, 4 * waves * sizeof(unsigned long long), h->stream));
     }
     if (const char *e = getenv("CT_RENDER_AHEAD")) {
         h->ahead = (uint32_t)std::min(65535, std::max(0, atoi(e)));
@@ -1698,6 +1704,7 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     ba.queue = sl.queue;
     ba.counters = h->d_counters;
     ba.stats = h->d_counters + kCounterCount + 1;
+    ba.timeline = h->d_timeline;
     if (suspend && short_batch(h, S) && h->serpentine) {
         ba.reverse = (uint32_t)(h->launch_no & 1u);
     }
@@ -2873,6 +2880,17 @@ extern "C" int ct_debug_memory(CtHandle h, uint64_t out[8])
     out[5] = h->dev.m_rows ? 1 : 0;
     out[6] = h->dev.m_rows ? (size_t)h->dev.brick_gy * h->dev.brick_gz * sizeof(uint2) : 0;
     out[7] = h->dev.m_rows ? (size_t)h->dev.m_cgxy * (size_t)((4 * h->dev.brick_gz + 7) >> h->dev.m_cshift) : 0;
+    return CT_OK;
+}
+
+extern "C" int ct_debug_timeline(CtHandle h, uint64_t *out, uint32_t waves)
+{
+    NEED(h);
+    const size_t have = (size_t)h->shape.blocks * h->shape.threads / 64u;
+    if (!h->d_timeline || !out || waves > have) {
+        return fail(h, CT_E_INVAL, "ct_debug_timeline: CT_TIMELINE=1 at ct_create, at most %zu waves", have);
+    }
+    HIPCHK(h, hipMemcpy(out, h->d_timeline, 4 * (size_t)waves * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CT_OK;
 }
 

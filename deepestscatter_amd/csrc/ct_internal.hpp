@@ -18,6 +18,7 @@ constexpr int kContWords = 16;      // words of a suspended path (render_persist
 constexpr int kContWordsDelta = 32; // the same for render_delta_kernel (its DDA state rides along)
 constexpr int kLeftWords = 8;        // words of a job handed to the next launch (BatchArgs::left_out)
 constexpr int kQueueFlag = 32;       // word of the queue array (its own 128-B line) that says "job list empty"
+constexpr int kQueueDone = 16;       // ... and the word that counts the queues whose last job has been taken
 constexpr int kQueueWords = 64;      // size of a queue array
 constexpr int kQueues = 8;          // one job queue per XCD (MI355X: 8 XCDs, each with its own L2)
 
@@ -90,6 +91,7 @@ struct BatchArgs {
     uint32_t out_offset;            // added to a compact result index (frame_stride != 0)
     unsigned long long *counters; // kCounterCount
     unsigned long long *stats;    // kStatCount
+    unsigned long long *timeline; // diagnostics (CT_TIMELINE=1), else NULL: per wave [start, end] on the 100 MHz wall clock
 };
 
 struct LaunchShape {

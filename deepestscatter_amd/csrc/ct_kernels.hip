@@ -921,8 +921,19 @@ CT_DEV bool take_job(const BatchArgs &ba, uint32_t lane, uint32_t &q_cur, uint32
             j = __builtin_amdgcn_readfirstlane(j);
             if (j < end - begin) {
                 job = ba.reverse ? end - 1u - j : begin + j;
-                if (begin + j + 1u == ba.n_jobs && lane == 0) {   // (the last job of the last queue, whichever way it is walked)
-                    __atomic_store_n(ba.queue + kQueueFlag, 1u, __ATOMIC_RELAXED); // see the suspend logic
+                if (j + 1u == end - begin && lane == 0) {
+                    // The last job of THIS queue.  The list is empty when that has happened to every queue that had jobs; whoever
+                    // finds it so raises the flag that the other waves look at now and then (see the suspend logic).  (Until round
+                    // 3 the flag went up with the job of the highest index, which is "the list is empty" for one queue only: with
+                    // per-XCD queues the waves did not look at it, and a busy wave learnt that nothing was left only when 16 of
+                    // its lanes had run out of work -- a launch of 10 subframes drained for 0.9 of its 4.3 ms.)
+                    uint32_t with_jobs = 0;
+                    for (uint32_t x = 0; x <= (uint32_t)kQueues; x++) {
+                        with_jobs += (ba.q_begin[x] != ba.q_begin[x + 1u]) ? 1u : 0u;
+                    }
+                    if (atomicAdd(&ba.queue[kQueueDone], 1u) + 1u == with_jobs) {
+                        __atomic_store_n(ba.queue + kQueueFlag, 1u, __ATOMIC_RELAXED);
+                    }
                 }
                 return true;
             }
@@ -1016,6 +1027,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     load_tables(sc, lds);
 
     const uint32_t lane = threadIdx.x & 63u;
+    if (ba.timeline && lane == 0u) {   // (diagnostics: when does this wave start?)
+        ba.timeline[4u * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))] = wall_clock64();
+    }
     f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), stepv = mk3(0, 0, 0), rad = mk3(0, 0, 0);
     uint32_t seed = 0, depth = 0, out_idx = 0;
     uint32_t work = 0;      // scheduler visits this path has cost so far (feeds the job order)
@@ -1081,11 +1095,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         }
     }
     const bool may_suspend = ba.cont_out != nullptr;
-    // one global list (queue 0 holds everything): a wave can see that it is empty without taking from it
+    // One global list (queue 0 holds everything): the waves look at the "list empty" flag now and then and hand their paths
+    // on as soon as it is up.  With per-XCD queues -- short launches -- they do NOT: a wave then learns that nothing is left
+    // when it runs out of work itself, and finishes what it holds meanwhile.  Round 3 tried the flag there too (it is raised
+    // when the last job of EVERY queue has been taken, take_job): the waves hand on 10 % more paths, more of them grow too old
+    // to be handed on again, and a 10-subframe launch takes 4.39 ms with a ring of 13 regions and 5.04 with the usual 6,
+    // against 4.34 without (tools/launch_timeline.py, profiles/r03y): the 0.9 ms in which such a launch drains are not idle
+    // time -- the waves that are left run the faster for being fewer.
     const bool single_queue = ba.q_begin[1] == ba.n_jobs;
 
     const unsigned long long t_start = STATS ? wall_clock64() : 0ull; // 100 MHz
     unsigned long long t_drained = 0;
+    bool tl_marked = false;
     uint32_t visit = 0;
     for (;;) {
         visit += 1;
@@ -1102,6 +1123,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 if (job.next == job.end) {
                     drained = true;
                 }
+            }
+        }
+        if (ba.timeline && drained && !tl_marked) {   // (diagnostics: when did this wave learn that no job is left, and what did it hold then?)
+            tl_marked = true;
+            const uint32_t live = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state != ST_IDLE));
+            const uint32_t old = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state != ST_IDLE && age >= ba.max_age));
+            if (lane == 0u) {
+                unsigned long long *tl = ba.timeline + 4u * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+                tl[2] = wall_clock64();
+                tl[3] = live | (old << 8) | ((job.next != job.end ? 1u : 0u) << 16);
             }
         }
         if (STATS) {
@@ -1446,6 +1477,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         }
     }
 
+    if (ba.timeline && lane == 0u) {   // (... and when does it end?)
+        ba.timeline[4u * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 1u] = wall_clock64();
+    }
     // flush counters: per-lane tallies -> one atomic per counter per wave
     uint32_t vals[3] = { c_dl, c_il, c_cap };
 #pragma unroll
@@ -1874,8 +1908,15 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
         }
     }
     const bool may_suspend = ba.cont_out != nullptr;
-    // one global list: only then does "the last job has been taken" (the flag) mean that every queue is empty
+    // One global list (queue 0 holds everything): the waves look at the "list empty" flag now and then and hand their paths
+    // on as soon as it is up.  With per-XCD queues -- short launches -- they do NOT: a wave then learns that nothing is left
+    // when it runs out of work itself, and finishes what it holds meanwhile.  Round 3 tried the flag there too (it is raised
+    // when the last job of EVERY queue has been taken, take_job): the waves hand on 10 % more paths, more of them grow too old
+    // to be handed on again, and a 10-subframe launch takes 4.39 ms with a ring of 13 regions and 5.04 with the usual 6,
+    // against 4.34 without (tools/launch_timeline.py, profiles/r03y): the 0.9 ms in which such a launch drains are not idle
+    // time -- the waves that are left run the faster for being fewer.
     const bool single_queue = ba.q_begin[1] == ba.n_jobs;
+    // one global list: only then does "the last job has been taken" (the flag) mean that every queue is empty
     uint32_t visit = 0;
 
     for (;;) {

@@ -1027,9 +1027,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     load_tables(sc, lds);
 
     const uint32_t lane = threadIdx.x & 63u;
+#ifdef CT_DIAG_TIMELINE   // (a build of its own, -DCT_DIAG_TIMELINE: in the product's kernel the three hooks cost 0.9 % of the headline)
     if (ba.timeline && lane == 0u) {   // (diagnostics: when does this wave start?)
         ba.timeline[4u * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))] = wall_clock64();
     }
+#endif
     f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), stepv = mk3(0, 0, 0), rad = mk3(0, 0, 0);
     uint32_t seed = 0, depth = 0, out_idx = 0;
     uint32_t work = 0;      // scheduler visits this path has cost so far (feeds the job order)
@@ -1106,7 +1108,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
 
     const unsigned long long t_start = STATS ? wall_clock64() : 0ull; // 100 MHz
     unsigned long long t_drained = 0;
+#ifdef CT_DIAG_TIMELINE
     bool tl_marked = false;
+#endif
     uint32_t visit = 0;
     for (;;) {
         visit += 1;
@@ -1125,6 +1129,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 }
             }
         }
+#ifdef CT_DIAG_TIMELINE
         if (ba.timeline && drained && !tl_marked) {   // (diagnostics: when did this wave learn that no job is left, and what did it hold then?)
             tl_marked = true;
             const uint32_t live = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state != ST_IDLE));
@@ -1135,6 +1140,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 tl[3] = live | (old << 8) | ((job.next != job.end ? 1u : 0u) << 16);
             }
         }
+#endif
         if (STATS) {
             st_iters += 1;
             if (drained && t_drained == 0) {
@@ -1477,9 +1483,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         }
     }
 
+#ifdef CT_DIAG_TIMELINE
     if (ba.timeline && lane == 0u) {   // (... and when does it end?)
         ba.timeline[4u * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 1u] = wall_clock64();
     }
+#endif
     // flush counters: per-lane tallies -> one atomic per counter per wave
     uint32_t vals[3] = { c_dl, c_il, c_cap };
 #pragma unroll

@@ -369,7 +369,7 @@ CT_API int ct_kernel_time(CtHandle h, double *render_ms_out, double *accumulate_
 CT_API int ct_debug_stats(CtHandle h, uint64_t out[64]);
 /* All `count` <= 72 diagnostic words (64..67: path conservation, 68..69: brick-line reuse of the march fetches). */
 CT_API int ct_debug_stats_ex(CtHandle h, uint64_t *out, uint32_t count);
-/* Diagnostics (CT_TIMELINE=1 in the environment at ct_create, MARCH estimator): [start, end, the time it learnt that no job is left, what it
+/* Diagnostics (a library built with -DCT_DIAG_TIMELINE, CT_TIMELINE=1 in the environment at ct_create, MARCH estimator): [start, end, the time it learnt that no job is left, what it
  * held then: live lanes | lanes too old to hand on << 8 | job unfinished << 16] of every wave of the last ENQUEUED estimator
  * launch, times on the device's 100 MHz wall clock, 4 * waves words (the launch that only resumes does not write it). */
 CT_API int ct_debug_timeline(CtHandle h, uint64_t *out, uint32_t waves);

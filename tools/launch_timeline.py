@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""When do the waves of an estimator launch start and end?  (CT_TIMELINE=1: every wave stores both on the 100 MHz wall clock.)
+"""When do the waves of an estimator launch start and end?  (A diagnostics build -- CT_EXTRA_FLAGS=-DCT_DIAG_TIMELINE python -m
+deepestscatter_amd.build --force -- with CT_TIMELINE=1: every wave stores both on the 100 MHz wall clock.)
 Steady state of enqueued launches of --spp subframes; the last one's timeline: how many waves are resident over time.
     CT_TIMELINE=1 python tools/launch_timeline.py [--spp 10] [--size 1024]"""
 import argparse, ctypes as C, json, os, sys

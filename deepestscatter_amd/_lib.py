@@ -4,10 +4,13 @@ own error code when no device is present."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libcloudtrace.so"
+# CT_LIBRARY: another build of the same library beside the product's (python -m deepestscatter_amd.build --variant ...): the
+# experiments build libcloudtrace_exp.so (tests/test_exchange.py, tools/) or an A/B build.  File name only, always in-tree.
+LIB_PATH = PKG / os.path.basename(os.environ.get("CT_LIBRARY", "libcloudtrace.so"))
 
 CT_ABI_VERSION = 1
 CT_OK, CT_E_INVAL, CT_E_HIP, CT_E_NOMEM, CT_E_STATE, CT_E_NODEVICE, CT_E_RCCL = 0, -1, -2, -3, -4, -5, -6

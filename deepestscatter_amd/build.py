@@ -61,6 +61,27 @@ def build_cli(force: bool = False, verbose: bool = False) -> Path:
     return CLI
 
 
+# Builds of the same sources beside the product's library (loaded with CT_LIBRARY=<file name>, deepestscatter_amd/_lib.py):
+#   exp   -DCT_EXPERIMENTS: the product plus the measured-and-rejected experiments (the two path-exchange kernels of
+#         csrc/ct_exchange.hpp; tests/test_exchange.py and the tools that A/B them)
+#   w8    the DELTA kernel as two 1024-thread blocks per CU, 8 waves per SIMD, 64 VGPRs (round-4 A/B)
+VARIANTS = {
+    "exp": ["-DCT_EXPERIMENTS"],
+    "w8": ["-DCT_DELTA_THREADS=1024", "-DCT_DELTA_WAVES=8"],
+}
+
+
+def build_variant(name: str, force: bool = False, verbose: bool = False) -> Path:
+    out = PKG / f"libcloudtrace_{name}.so"
+    deps = [CSRC / s for s in SOURCES] + HEADERS
+    if force or not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
+        cmd = [hipcc(), *FLAGS, *VARIANTS[name], "-o", str(out), *[str(CSRC / s) for s in SOURCES], "-lz", "-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=str(CSRC))
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     if force or needs_build():
         # CT_EXTRA_FLAGS: e.g. -DCT_DEBUG_BOUNDS (device-side index checks that report instead of faulting)
@@ -73,4 +94,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        print(build_variant(sys.argv[sys.argv.index("--variant") + 1], force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -35,7 +35,7 @@ struct CtHandle_ {
 
     // device memory
     uint8_t *d_density = nullptr, *d_inscatter = nullptr, *d_dist = nullptr, *d_dist_tmp = nullptr, *d_majorant = nullptr, *d_maj_cells = nullptr, *d_maj_codes = nullptr;
-    uint8_t *d_dbricks = nullptr, *d_ibricks = nullptr, *d_mbricks = nullptr;
+    uint8_t *d_dbricks = nullptr, *d_ibricks = nullptr, *d_mbricks = nullptr, *d_tbricks = nullptr;
     uint2 *d_mrows = nullptr;          // sparse march bricks: extent of every brick row (DevScene::m_rows)
     uint8_t *d_mcoarse = nullptr;      // ... and the clearance of the coarse cells outside the extents
     size_t mbricks_dense_bytes = 0, mbricks_bytes = 0;
@@ -364,7 +364,7 @@ static void release(CtHandle h)
     if (h->stream) {
         hipStreamSynchronize(h->stream);
     }
-    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
+    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_tbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_group_rank, h->d_group_order, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->d_hit, h->d_cost_plane, h->d_timeline, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
@@ -528,6 +528,10 @@ static int create_impl(const CtScene *s, CtHandle h)
     }
     if (s->estimator == CT_EST_DELTA) {
         h->job_work = 48.f;     // (its cost unit is a bounce; 16 measured 0.4 % slower there)
+        d.delta_nee = 0u;
+        if (const char *e = getenv("CT_DELTA_NEE")) {   // render_delta_kernel<.., NEE>: where a collision's two lookups come from
+            d.delta_nee = (uint32_t)std::min(2, std::max(0, atoi(e)));
+        }
     }
     if (const char *e = getenv("CT_JOB_WORK")) {
         h->job_work = (float)std::max(1.0, atof(e));
@@ -736,6 +740,29 @@ static int create_impl(const CtScene *s, CtHandle h)
         }
         if (e == hipSuccess) {
             e = launch_build_bricks(h->d_inscatter, nx, ny, nz, bbias, (int)bgx, (int)bgy, (int)bgz, h->d_ibricks, h->stream);
+        }
+        if (e == hipSuccess && s->estimator == CT_EST_DELTA && d.delta_nee == 2u) {
+            // twin bricks (DevScene::tbricks): density and shadow volume of 3^3 base texels in one line, over the texel range
+            // of the apron bricks (which is that of the majorant cells: every position a flight can reach)
+            const int tbias = ((bbias + 2) / 3) * 3;
+            const int64_t tgx = ((int64_t)nx + bbias + tbias + 2) / 3 + 1, tgy = ((int64_t)ny + bbias + tbias + 2) / 3 + 1,
+                          tgz = ((int64_t)nz + bbias + tbias + 2) / 3 + 1;
+            if (tgx * tgy * tgz >= (1ll << 31) || tgx * tgy >= (1ll << 24) || (int64_t)std::max({ nx, ny, nz }) + 2 * tbias >= (1 << 15)) {
+                hipFree(tmp_a);
+                hipFree(tmp_b);
+                return fail(h, CT_E_INVAL, "volume too large for 32-bit brick indices");
+            }
+            if (hipMalloc(&h->d_tbricks, (size_t)(tgx * tgy * tgz) * 128) != hipSuccess) {
+                hipFree(tmp_a);
+                hipFree(tmp_b);
+                return fail(h, CT_E_NOMEM, "out of device memory (twin bricks)");
+            }
+            e = launch_build_twin_bricks(h->d_density, h->d_inscatter, nx, ny, nz, tbias, (int)tgx, (int)tgy, (int)tgz, h->d_tbricks, h->stream);
+            d.tbricks = h->d_tbricks;
+            d.t_bias = tbias;
+            d.t_gx = (int32_t)tgx;
+            d.t_gy = (int32_t)tgy;
+            d.t_gz = (int32_t)tgz;
         }
         const hipError_t e2 = hipStreamSynchronize(h->stream);
         // Sparse storage (BASELINE.json configs[4]: "1024^3 sparse brick-compressed density"): CT_FLAG_SPARSE_BRICKS, or

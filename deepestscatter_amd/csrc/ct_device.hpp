@@ -135,6 +135,17 @@ struct DevScene {
     // [-brick_bias, n + brick_bias) per axis, x-fastest.  mc_shift is the smallest value >= 2 for which the grid
     // has at most kMajCellsMax cells, so that every block keeps the whole grid in LDS and a flight crosses cells
     // without touching memory (oracle/ct_oracle.c, DELTA header: same grid, same majorants).
+    // Twin bricks (DELTA estimator): one 128-byte line per 3x3x3 base texels.  Bytes 0..63 = the 4x4x4 DENSITY texels
+    // [3b, 3b+3]^3 (clamp-to-edge applied) at byte lz*16 + ly*4 + lx, bytes 64..127 = the SHADOW volume's texels at the same
+    // places.  A Woodcock collision is a point: the density lookup that decides it (cloud.cuh:58-62) and the NEE lookup of the
+    // shadow volume that follows when it is real (cloud.cuh:146-158) have the same footprint, so with both halves in ONE line the
+    // second lookup never leaves the line the first one brought -- one line fill per scatter event instead of two.  A footprint
+    // based at (lx,ly,lz) in [0,2]^3 is read with two unaligned 8-byte loads at o = lz*16 + ly*4 + lx (bytes 0,1 and 4,5 = rows
+    // y, y+1) and at o + 14 (bytes 2,3 and 6,7 = the same rows one slice up): both stay inside their 64-byte half.
+    const uint8_t *tbricks;
+    int32_t t_bias;             // added to a texel index to make it non-negative (multiple of 3)
+    int32_t t_gx, t_gy, t_gz;   // bricks per axis
+    uint32_t delta_nee;         // render_delta_kernel<.., NEE>: 0, 1 or 2 (2 only with tbricks)
     const uint8_t *maj_cells;
     const uint8_t *maj_codes;   // per cell q = min(3, 4*min/max) of its texels: texel value (q*M) >> 2 bounds the cell from below
     int32_t mc_shift, mc_gx, mc_gy, mc_gz;
@@ -347,6 +358,67 @@ CT_DEV uint2 fetch_cell_in_grid(const DevScene &sc, const uint8_t *bricks, f3 p,
     const int32_t iy = min(max(floor_to_int(y), lo), 4 * sc.brick_gy - 1 + lo);
     const int32_t iz = min(max(floor_to_int(z), lo), 4 * sc.brick_gz - 1 + lo);
     return load_footprint_meta(sc, bricks, ix, iy, iz, meta);
+}
+
+// ---- the DELTA kernel's two fetch layouts (render_delta_kernel<.., NEE>) ----------------------------------------------
+// Byte offset of the footprint of `p` in the apron-brick arrays (density and shadow volume share it), texel index clamped
+// to the grid like fetch_cell_in_grid.
+CT_DEV size_t apron_offset_in_grid(const DevScene &sc, f3 p)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    const int32_t lo = -sc.brick_bias;
+    const uint32_t ux = (uint32_t)(min(max(floor_to_int(x), lo), 4 * sc.brick_gx - 1 + lo) + sc.brick_bias);
+    const uint32_t uy = (uint32_t)(min(max(floor_to_int(y), lo), 4 * sc.brick_gy - 1 + lo) + sc.brick_bias);
+    const uint32_t uz = (uint32_t)(min(max(floor_to_int(z), lo), 4 * sc.brick_gz - 1 + lo) + sc.brick_bias);
+    const uint32_t brick = __umul24(uz >> 2, (uint32_t)sc.brick_gxy) + __umul24(uy >> 2, (uint32_t)sc.brick_gx) + (ux >> 2);
+    const uint32_t local = __umul24(uz & 3u, 25u) + __umul24(uy & 3u, 5u) + (ux & 3u);
+    return ((size_t)brick << 7) | local;
+}
+// The two 8-byte loads of a footprint, not yet combined (a load that is consumed later leaves the wave free meanwhile).
+struct RawCell {
+    uint2 a, c;
+};
+CT_DEV RawCell load_raw_apron(const uint8_t *q)
+{
+    RawCell r;
+    __builtin_memcpy(&r.a, q, 8);
+    __builtin_memcpy(&r.c, q + 25, 8);
+    return r;
+}
+CT_DEV uint2 combine_apron(const RawCell &r)
+{
+    return make_uint2(__builtin_amdgcn_perm(r.a.y, r.a.x, 0x06050100u), __builtin_amdgcn_perm(r.c.y, r.c.x, 0x06050100u));
+}
+// Twin bricks (DevScene::tbricks): offset of the DENSITY footprint of `p`; the shadow volume's is 64 bytes further.
+CT_DEV size_t twin_offset_in_grid(const DevScene &sc, f3 p)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    const int32_t lo = -sc.t_bias;
+    const uint32_t ux = (uint32_t)(min(max(floor_to_int(x), lo), 3 * sc.t_gx - 1 + lo) + sc.t_bias);
+    const uint32_t uy = (uint32_t)(min(max(floor_to_int(y), lo), 3 * sc.t_gy - 1 + lo) + sc.t_bias);
+    const uint32_t uz = (uint32_t)(min(max(floor_to_int(z), lo), 3 * sc.t_gz - 1 + lo) + sc.t_bias);
+    const uint32_t bx = __umul24(ux, 43691u) >> 17, by = __umul24(uy, 43691u) >> 17, bz = __umul24(uz, 43691u) >> 17; // u / 3, exact for u < 2^15
+    const uint32_t lx = ux - __umul24(bx, 3u), ly = uy - __umul24(by, 3u), lz = uz - __umul24(bz, 3u);
+    const uint32_t brick = __umul24(__umul24(bz, (uint32_t)sc.t_gy) + by, (uint32_t)sc.t_gx) + bx;
+    const uint32_t local = (lz << 4) + (ly << 2) + lx;
+#ifdef CT_DEBUG_BOUNDS
+    if (bx >= (uint32_t)sc.t_gx || by >= (uint32_t)sc.t_gy || bz >= (uint32_t)sc.t_gz) {
+        printf("CT_DEBUG_BOUNDS twin-brick texel (%u,%u,%u) outside the grid\n", ux, uy, uz);
+        return 0;
+    }
+#endif
+    return ((size_t)brick << 7) | local;
+}
+CT_DEV RawCell load_raw_twin(const uint8_t *q)
+{
+    RawCell r;
+    __builtin_memcpy(&r.a, q, 8);
+    __builtin_memcpy(&r.c, q + 14, 8);
+    return r;
+}
+CT_DEV uint2 combine_twin(const RawCell &r)
+{
+    return make_uint2(__builtin_amdgcn_perm(r.a.y, r.a.x, 0x05040100u), __builtin_amdgcn_perm(r.c.y, r.c.x, 0x07060302u));
 }
 
 // A lane's own one-entry cache in front of fetch_cell: consecutive scatter events of a path are about a mean

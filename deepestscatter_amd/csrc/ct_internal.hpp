@@ -122,6 +122,8 @@ __host__ __device__ inline uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_
 
 hipError_t launch_build_bricks(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
                                uint8_t *bricks, hipStream_t stream);
+hipError_t launch_build_twin_bricks(const uint8_t *density, const uint8_t *shadow, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
+                                    uint8_t *bricks, hipStream_t stream);
 hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
                              uint8_t *dist, uint8_t *scratch, uint8_t *majorant, hipStream_t stream);
 hipError_t launch_majorant_cells(const uint8_t *texels, int nx, int ny, int nz, int bias, int shift, int gx, int gy, int gz,

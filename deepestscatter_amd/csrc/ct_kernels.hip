@@ -62,6 +62,35 @@ __global__ void build_bricks_kernel(const uint8_t *__restrict__ t, int nx, int n
     }
 }
 
+// Twin bricks (DevScene::tbricks): one thread per byte; brick b holds the texels [3b - bias, 3b - bias + 3]^3 of the density
+// (bytes 0..63) and of the shadow volume (bytes 64..127), clamp-to-edge applied, at byte lz*16 + ly*4 + lx of each half.
+__global__ void build_twin_bricks_kernel(const uint8_t *__restrict__ density, const uint8_t *__restrict__ shadow, int nx, int ny, int nz,
+                                         int bias, uint8_t *__restrict__ bricks, int gx, int gy, int gz)
+{
+    const int64_t total = (int64_t)gx * gy * gz * 128;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i >> 7;
+        const int o = (int)(i & 63);
+        const int lx = o & 3, ly = (o >> 2) & 3, lz = o >> 4;
+        const int x = (int)(b % gx) * 3 + lx - bias;
+        const int y = (int)((b / gx) % gy) * 3 + ly - bias;
+        const int z = (int)(b / ((int64_t)gx * gy)) * 3 + lz - bias;
+        const int xc = min(max(x, 0), nx - 1), yc = min(max(y, 0), ny - 1), zc = min(max(z, 0), nz - 1);
+        const uint8_t *t = (i & 64) ? shadow : density;
+        bricks[i] = t[((size_t)zc * ny + yc) * nx + xc];
+    }
+}
+
+hipError_t launch_build_twin_bricks(const uint8_t *density, const uint8_t *shadow, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
+                                    uint8_t *bricks, hipStream_t stream)
+{
+    const int64_t total = (int64_t)gx * gy * gz * 128;
+    const int threads = 256;
+    const int blocks = (int)((total + threads - 1) / threads < 65536 ? (total + threads - 1) / threads : 65536);
+    hipLaunchKernelGGL(build_twin_bricks_kernel, dim3(blocks), dim3(threads), 0, stream, density, shadow, nx, ny, nz, bias, bricks, gx, gy, gz);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_bricks(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
                                uint8_t *bricks, hipStream_t stream)
 {
@@ -681,6 +710,24 @@ CT_DEV NeeLoads in_scattering_issue(const DevScene &sc, f3 pos, f3 dir, bool cho
     n.w = fract_(x);
     uint32_t meta_unused;
     n.cell = fetch_cell(sc, sc.ibricks, pos, meta_unused);
+    return n;
+}
+
+// Only the phase-table half of in_scattering_issue (the caller has the shadow-volume footprint already).
+CT_DEV NeeLoads in_scattering_issue_phase(const DevScene &sc, f3 dir, bool chopped)
+{
+    NeeLoads n;
+    const float cos_light = dot3(mk3(sc.nlx, sc.nly, sc.nlz), dir);
+    const float u = (cos_light + 1) / 2;
+    const float *table = chopped ? sc.chopped : sc.mie;
+    const float x = fmaf(u, (float)kMieN, -0.5f);
+    const int32_t i = (int32_t)floorf(x);
+    float2 pair;
+    __builtin_memcpy(&pair, table + min(max(i, 0), kMieN - 2), sizeof pair);
+    n.a = (i > kMieN - 2) ? pair.y : pair.x;
+    n.b = (i < 0) ? pair.x : pair.y;
+    n.w = fract_(x);
+    n.cell = make_uint2(0u, 0u);
     return n;
 }
 
@@ -1680,7 +1727,13 @@ hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const fl
 //     u' * sigma_bar < sigma(p).  (Several crossings per visit were tried: the lanes that keep crossing
 //     hold up the wave; one step per visit and bursts of 3 visits measured best.)
 // =============================================================================================
-constexpr int kDeltaThreads = 768;
+#ifndef CT_DELTA_THREADS
+#define CT_DELTA_THREADS 768   // (A/B builds: -DCT_DELTA_THREADS=1024 -DCT_DELTA_WAVES=8 = two 1024-thread blocks per CU, 8 waves per SIMD, 64 VGPRs)
+#endif
+#ifndef CT_DELTA_WAVES
+#define CT_DELTA_WAVES 6
+#endif
+constexpr int kDeltaThreads = CT_DELTA_THREADS;
 
 struct Dda {
     f3 org;            // origin of the flight (box coordinates), positions are fma(dir, t, org)
@@ -1833,8 +1886,17 @@ hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primar
     return hipGetLastError();
 }
 
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6))) void render_delta_kernel(DevScene sc, BatchArgs ba)
+// NEE selects where a collision's two lookups come from (same values, same radiance -- only the loads differ):
+//   0  density from the 4^3 apron bricks when the collision is drawn, the shadow volume from its own apron bricks in the
+//      scatter phase (rounds 1-3);
+//   1  the same two arrays, but the shadow-volume footprint is REQUESTED in the tracking visit, as soon as the collision is
+//      known to be real, and consumed in the scatter phase: its miss runs beside the rest of the visit instead of in front
+//      of the bounce;
+//   2  twin bricks (DevScene::tbricks): both footprints in one 128-byte line, the shadow half requested like in 1 -- an L1/L2
+//      hit on the line the density lookup has just brought, or that line's one fill when the lower bound made the lookup
+//      unnecessary.
+template <int MODE, bool STATS, int NEE>
+__global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(CT_DELTA_WAVES))) void render_delta_kernel(DevScene sc, BatchArgs ba)
 {
     // 24 KiB of Mie tables + 40 KiB of majorants + 10 KiB of lower-bound codes + 2 KiB per block of 768 threads:
     // two blocks per CU, 6 waves per SIMD
@@ -1871,6 +1933,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
     Dda dda{};
     uint32_t seed = 0, depth = 0, out_idx = 0;
     int state = ST_IDLE;
+    RawCell nee_raw{};   // NEE != 0: the shadow-volume footprint of the collision this lane waits to scatter at (state == ST_BOUNCE)
 
     JobState job{ 0, 0, 0, 0, 0, 0 };   // the current job and the samples left in it
     bool left_done = false;
@@ -1912,6 +1975,11 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             age = w6.y;
             if (STATS) {
                 iv_resumed += 1;
+            }
+            if (NEE != 0 && state == ST_BOUNCE) {
+                // suspended between its collision and its bounce: the footprint the tracking visit had requested went with the launch
+                nee_raw = (NEE == 1) ? load_raw_apron(sc.ibricks + apron_offset_in_grid(sc, pos))
+                                     : load_raw_twin(sc.tbricks + twin_offset_in_grid(sc, pos) + 64);
             }
         }
     }
@@ -2053,7 +2121,12 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
             }
             if (state == ST_BOUNCE) {
                 const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
-                const NeeLoads nee = in_scattering_issue(sc, pos, dir, chopped);
+                NeeLoads nee;
+                if (NEE == 0) {
+                    nee = in_scattering_issue(sc, pos, dir, chopped);
+                } else {
+                    nee = in_scattering_issue_phase(sc, dir, chopped);
+                }
                 c_il += 1;
                 bool go = (MODE != 2);
                 if (go) {
@@ -2063,6 +2136,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                         c_cap += 1;
                         go = false;
                     }
+                }
+                if (NEE != 0) {
+                    nee.cell = (NEE == 1) ? combine_apron(nee_raw) : combine_twin(nee_raw);
                 }
                 rad = add3(rad, in_scattering_finish(sc, nee, pos));
                 if (go) {
@@ -2119,9 +2195,24 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                     const float z = u24_to_float(lcg24(seed));
                     // sigma(p) >= sigma_low throughout the cell: below it the collision is real without a lookup
                     bool real = z * sigma_bar < sigma_low;
+                    // (NEE != 0: where the collision's footprints are -- the same offset in the density's and the shadow volume's
+                    // apron bricks, or the density half of the twin line; inside the box the clamp to the grid changes nothing)
+                    size_t off = 0;
+                    if (NEE == 1) {
+                        off = apron_offset_in_grid(sc, p);
+                    } else if (NEE == 2) {
+                        off = twin_offset_in_grid(sc, p);
+                    }
                     if (!real) {
-                        uint32_t meta_unused;
-                        const uint2 cell = fetch_cell_in_grid(sc, sc.dbricks, p, meta_unused);
+                        uint2 cell;
+                        if (NEE == 0) {
+                            uint32_t meta_unused;
+                            cell = fetch_cell_in_grid(sc, sc.dbricks, p, meta_unused);
+                        } else if (NEE == 1) {
+                            cell = combine_apron(load_raw_apron(sc.dbricks + off));
+                        } else {
+                            cell = combine_twin(load_raw_twin(sc.tbricks + off));
+                        }
                         c_dl += 1;
                         if (STATS) {
                             st_fetch += 1;
@@ -2133,6 +2224,11 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
                         pos = p;
                         if (in_box(sc, pos)) {
                             state = ST_BOUNCE;
+                            if (NEE == 1) {
+                                nee_raw = load_raw_apron(sc.ibricks + off);
+                            } else if (NEE == 2) {
+                                nee_raw = load_raw_twin(sc.tbricks + off + 64);
+                            }
                         } else {
                             ended = true;
                         }
@@ -2275,22 +2371,39 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(6
     }
 }
 
+template <bool STATS, int NEE>
+static void launch_render_delta_mode(const DevScene &sc, const BatchArgs &ba, dim3 grid, dim3 block, hipStream_t stream)
+{
+    switch (sc.mode) {
+    case 0: hipLaunchKernelGGL((render_delta_kernel<0, STATS, NEE>), grid, block, 0, stream, sc, ba); break;
+    case 1: hipLaunchKernelGGL((render_delta_kernel<1, STATS, NEE>), grid, block, 0, stream, sc, ba); break;
+    default: hipLaunchKernelGGL((render_delta_kernel<2, STATS, NEE>), grid, block, 0, stream, sc, ba); break;
+    }
+}
+
+static void launch_render_delta_nee(const DevScene &sc, const BatchArgs &ba, dim3 grid, dim3 block, hipStream_t stream, bool stats)
+{
+    // (DevScene::delta_nee: 2 needs the twin bricks, which ct_create builds only when it chose that layout)
+    const int nee = sc.delta_nee == 2u && sc.tbricks ? 2 : (sc.delta_nee == 1u ? 1 : 0);
+    if (stats) {
+        switch (nee) {
+        case 0: launch_render_delta_mode<true, 0>(sc, ba, grid, block, stream); break;
+        case 1: launch_render_delta_mode<true, 1>(sc, ba, grid, block, stream); break;
+        default: launch_render_delta_mode<true, 2>(sc, ba, grid, block, stream); break;
+        }
+    } else {
+        switch (nee) {
+        case 0: launch_render_delta_mode<false, 0>(sc, ba, grid, block, stream); break;
+        case 1: launch_render_delta_mode<false, 1>(sc, ba, grid, block, stream); break;
+        default: launch_render_delta_mode<false, 2>(sc, ba, grid, block, stream); break;
+        }
+    }
+}
+
 hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream)
 {
     const dim3 grid(shape.blocks), block(shape.threads);
-    if (shape.stats) {
-        switch (sc.mode) {
-        case 0: hipLaunchKernelGGL((render_delta_kernel<0, true>), grid, block, 0, stream, sc, ba); break;
-        case 1: hipLaunchKernelGGL((render_delta_kernel<1, true>), grid, block, 0, stream, sc, ba); break;
-        default: hipLaunchKernelGGL((render_delta_kernel<2, true>), grid, block, 0, stream, sc, ba); break;
-        }
-    } else {
-        switch (sc.mode) {
-        case 0: hipLaunchKernelGGL((render_delta_kernel<0, false>), grid, block, 0, stream, sc, ba); break;
-        case 1: hipLaunchKernelGGL((render_delta_kernel<1, false>), grid, block, 0, stream, sc, ba); break;
-        default: hipLaunchKernelGGL((render_delta_kernel<2, false>), grid, block, 0, stream, sc, ba); break;
-        }
-    }
+    launch_render_delta_nee(sc, ba, grid, block, stream, shape.stats);
     return hipGetLastError();
 }
 
@@ -2304,7 +2417,7 @@ LaunchShape persistent_shape(int device, bool delta)
         // as many blocks per CU as the kernel's registers and LDS admit: MARCH 512 threads / 40 KiB,
         // DELTA 768 threads / 64 KiB
         int per_cu = 0;
-        const hipError_t e = delta ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_delta_kernel<0, false>, kDeltaThreads, 0)
+        const hipError_t e = delta ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_delta_kernel<0, false, 0>, kDeltaThreads, 0)
                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_persistent_kernel<0, false, false>, 512, 0);
         if (e != hipSuccess || per_cu < 1) {
             per_cu = delta ? 2 : 3;

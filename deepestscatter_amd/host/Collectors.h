@@ -94,14 +94,16 @@ namespace DeepestScatter
         {
             for (int k = 0; k < 3; k++) point[k] = viewDirection[k] = 0.f;
             size_t i = 0;
-            auto varint = [&]() { uint64_t v = 0; int s = 0; while (true) { const uint8_t c = (uint8_t)b.at(i++); v |= (uint64_t)(c & 0x7f) << s; if (!(c & 0x80)) return v; s += 7; } };
+            auto varint = [&]() { uint64_t v = 0; int s = 0; while (true) { const uint8_t c = (uint8_t)b.at(i++); v |= (uint64_t)(c & 0x7f) << s; if (!(c & 0x80)) return v; s += 7; if (s > 63) throw std::runtime_error("varint longer than ten bytes in a ScatterSample record"); } };
             while (i < b.size())
             {
                 const uint8_t tag = (uint8_t)b[i++];
                 if (tag == 0x08) { varint(); continue; }
                 if (tag != 0x12 && tag != 0x1a) throw std::runtime_error("unexpected tag in a ScatterSample record");
                 float* dst = tag == 0x12 ? point : viewDirection;
-                const size_t n = (size_t)varint(), end = i + n;
+                const size_t n = (size_t)varint();
+                if (n > b.size() - i) throw std::runtime_error("Vector3 longer than its ScatterSample record");
+                const size_t end = i + n;
                 while (i < end)
                 {
                     const int k = ((uint8_t)b.at(i) >> 3) - 1;

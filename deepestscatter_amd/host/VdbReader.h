@@ -45,6 +45,22 @@ struct Coord {
 
 constexpr uint32_t COMPRESS_ZIP = 1, COMPRESS_ACTIVE_MASK = 2, COMPRESS_BLOSC = 4;
 
+// Files are untrusted.  A root child's or root tile's origin read from the file must be a multiple of 4096 within
+// +-2^30: every coordinate derived from it (child origins, voxel positions, box edges) then fits an int32 without overflow.
+// And the dense box the loader fills is capped per axis (the reference has no cap and would exhaust memory; 2048^3 floats
+// are 34 GB).  The sanitizer build lowers the cap so that the rejection is exercised without the allocation
+// (tests/sanitize/Makefile).
+#ifndef CT_VDB_MAX_EDGE
+#define CT_VDB_MAX_EDGE 2048
+#endif
+inline void checkRootOrigin(const Coord& o)
+{
+    const int32_t lim = 1 << 30;
+    if (o.x < -lim || o.x > lim || o.y < -lim || o.y > lim || o.z < -lim || o.z > lim || ((o.x | o.y | o.z) & 4095) != 0) {
+        throw std::runtime_error("vdb: root-level origin out of range or not a multiple of 4096");
+    }
+}
+
 // ---- a byte cursor over the whole file ----------------------------------------------------------------
 class Cursor {
 public:
@@ -58,7 +74,7 @@ public:
     void read(void* dst, size_t n)
     {
         if (n > buf.size() - pos) throw std::runtime_error("vdb: unexpected end of file");
-        std::memcpy(dst, buf.data() + pos, n);
+        if (n) std::memcpy(dst, buf.data() + pos, n);   // (n == 0 comes with dst == nullptr: an empty vector's data())
         pos += n;
     }
     const uint8_t* take(size_t n)
@@ -515,6 +531,7 @@ inline FloatGrid readFirstFloatGrid(const std::string& path)
     for (uint32_t i = 0; i < numTiles; i++) {
         Coord o;
         in.read(&o, 12);
+        checkRootOrigin(o);
         const float v = in.get<float>();
         const bool active = in.get<uint8_t>() != 0;
         g.tiles.push_back(Tile{ o, 4096, v, active });
@@ -523,6 +540,7 @@ inline FloatGrid readFirstFloatGrid(const std::string& path)
     for (uint32_t i = 0; i < numChildren; i++) {
         Coord o;
         in.read(&o, 12);
+        checkRootOrigin(o);
         detail::readInternal<5, 7>(in, g, o, fromHalf, leafOrder);
     }
     // Tree::readBuffers -> LeafNode::readBuffers, in the order of the topology
@@ -550,7 +568,9 @@ inline void loadVolumeTexture(const std::string& path, std::vector<uint8_t>& tex
     // boundingBox.expandBy(1); min = box.min(); max = box.max() + 1; size = max - min
     const Coord mn{ lo.x - 1, lo.y - 1, lo.z - 1 };
     const int64_t sx = (int64_t)hi.x + 2 - mn.x, sy = (int64_t)hi.y + 2 - mn.y, sz = (int64_t)hi.z + 2 - mn.z;
-    if (sx > 2048 || sy > 2048 || sz > 2048) throw std::runtime_error("vdb: active bounding box larger than 2048 voxels");
+    if (sx > CT_VDB_MAX_EDGE || sy > CT_VDB_MAX_EDGE || sz > CT_VDB_MAX_EDGE) {
+        throw std::runtime_error("vdb: active bounding box larger than " + std::to_string(CT_VDB_MAX_EDGE) + " voxels");
+    }
     dims = { (uint32_t)sx, (uint32_t)sy, (uint32_t)sz };
     std::vector<float> dense((size_t)(sx * sy * sz), g.background); // [z][y][x]
     auto paste = [&](Coord o, int32_t dim, auto&& valueAt) {

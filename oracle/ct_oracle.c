@@ -143,13 +143,27 @@ static inline float lerpf(float a, float b, float t) { return fmaf(t, b - a, a);
 /* Filter weight: frac(x) = x - floor(x), kept strictly below 1 (a tiny negative x would
  * otherwise round to 1.0f); this is also what gfx950's v_fract_f32 returns. */
 static inline float fracf(float x, float fl) { return fminf(x - fl, 0x1.fffffep-1f); }
+/* The weight a filtered fetch uses.  Default (this repository's specification, shared with the kernels): the exact float
+ * fraction.  -DORC_TEX_FIXED8 (libct_oracle_fixed8.so): what the reference's hardware does instead -- the CUDA C Programming
+ * Guide's appendix "Texture Fetching", linear filtering: "alpha, beta and gamma are stored in 9-bit fixed point format with
+ * 8 bits of fractional value (so 1.0 is exactly represented)", i.e. the fraction rounded to a multiple of 1/256.  The guide
+ * does not state the rounding; round-to-nearest is used here (truncation moves every weight by up to 1/256 instead of
+ * 1/512, the same order).  The texture unit's internal arithmetic is not published either: the nested lerps below stay.
+ * This build exists to MEASURE how far the repository's exact-weight specification is from a sampler like the reference's
+ * (samplers: VDBCloud.cpp:123-135, Mie.cpp:8229-8240); it is not a parity target -- paths branch differently, so it agrees
+ * with the default build statistically only (tests/test_oracle_basics.py, tests/test_parity_gaps.py). */
+#ifdef ORC_TEX_FIXED8
+static inline float filter_weight(float x, float fl) { return rintf(fracf(x, fl) * 256.0f) * (1.0f / 256.0f); }
+#else
+static inline float filter_weight(float x, float fl) { return fracf(x, fl); }
+#endif
 
 /* tex1D on a float buffer: linear, clamp, normalised coords (Mie.cpp:8229-8240). */
 ORC_API float orc_tex1d(const float *t, uint32_t n, float u)
 {
     const float x = fmaf(u, (float)n, -0.5f);
     const float fl = floorf(x);
-    const float w = fracf(x, fl);
+    const float w = filter_weight(x, fl);
     const int32_t i = (int32_t)fl;
     const float a = t[clampi(i, 0, (int32_t)n - 1)];
     const float b = t[clampi(i + 1, 0, (int32_t)n - 1)];
@@ -171,7 +185,7 @@ static inline float tex3_fetch(const Tex3 *t, v3 p)
     const float y = fmaf(p.y, t->sy, -0.5f);
     const float z = fmaf(p.z, t->sz, -0.5f);
     const float flx = floorf(x), fly = floorf(y), flz = floorf(z);
-    const float wx = fracf(x, flx), wy = fracf(y, fly), wz = fracf(z, flz);
+    const float wx = filter_weight(x, flx), wy = filter_weight(y, fly), wz = filter_weight(z, flz);
     const int32_t ix = (int32_t)flx, iy = (int32_t)fly, iz = (int32_t)flz;
     const int32_t x0 = clampi(ix, 0, t->nx - 1), x1 = clampi(ix + 1, 0, t->nx - 1);
     const int32_t y0 = clampi(iy, 0, t->ny - 1), y1 = clampi(iy + 1, 0, t->ny - 1);

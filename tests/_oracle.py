@@ -96,13 +96,20 @@ def lib(fast=False):
     key = "fma" if (fast and _cpu_has("fma") and _cpu_has("avx2")) else "base"
     if fast == "libm":
         key = "libm"      # the restatement on the C library's math (statistical agreement only; ORC_LIBM in ct_oracle.c)
+    if fast == "fixed8":
+        key = "fixed8"    # ... with 1.8 fixed-point filter weights, like the reference's texture unit (ORC_TEX_FIXED8)
     if _LIB is None:
         _LIB = {}
     if key in _LIB:
         return _LIB[key]
-    name = {"fma": "libct_oracle_fma.so", "libm": "libct_oracle_libm.so"}.get(key, "libct_oracle.so")
+    name = {"fma": "libct_oracle_fma.so", "libm": "libct_oracle_libm.so", "fixed8": "libct_oracle_fixed8.so"}.get(key, "libct_oracle.so")
     path = ORACLE_DIR / name
     build(force=not path.exists())   # also rebuilds a library older than its source before it is loaded
+    if os.environ.get("CT_ORACLE_SANITIZE") == "1" and key in ("base", "fma"):
+        # tests/test_sanitizers.py: this process has libasan preloaded and runs the oracle's own tests on the
+        # AddressSanitizer + UndefinedBehaviorSanitizer build of the same source (make -C oracle asan)
+        subprocess.run(["make", "-C", str(ORACLE_DIR), "-s", "asan"], check=True)
+        path = ORACLE_DIR / "libct_oracle_asan.so"
     L = C.CDLL(str(path))
     f32p = C.POINTER(C.c_float)
     L.orc_tea4.restype = C.c_uint32

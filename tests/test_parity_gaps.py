@@ -158,6 +158,48 @@ def test_march_kernel_meets_the_north_star_tolerance_against_an_oracle_on_libm_m
     # measured: window 8.5e-4, median pixel 2e-5, 97.8 % of the pixels within 1e-3; the rest are pixels where ONE of the
     # 1024 paths took another branch on a last ulp (a bright path moves a pixel by up to 1e-2) -- "per pixel" is only
     # reachable with the identical arithmetic, which is why the contract is bit-exactness against an oracle that shares it
-    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 2e-3
+    window = np.linalg.norm(got - want) / np.linalg.norm(want)
+    print(f"\nMARCH kernel vs oracle on libm math, 128^3, {n}x{n} window, 1024 spp: window relL2 {window:.2e}, median pixel "
+          f"{np.median(per_pixel):.1e}, pixels within 1e-3: {(per_pixel <= 1e-3).mean():.3f}, worst pixel {per_pixel.max():.1e}")
+    # The north star's number, asserted as what it can mean across math libraries: the WINDOW is within 1e-3 (measured
+    # 8.5e-4).  Pixel by pixel it is not -- 2 % of the pixels hold a path that branched differently -- and that distribution
+    # is reported above and bounded loosely below; DESIGN.md section 2 carries the table.
+    assert window <= 1e-3
     assert np.median(per_pixel) <= 1e-4 and (per_pixel <= 1e-3).mean() >= 0.95 and per_pixel.max() <= 5e-2, \
         (np.median(per_pixel), (per_pixel <= 1e-3).mean(), per_pixel.max())
+
+
+def test_march_kernel_against_an_oracle_with_fixed_point_filter_weights():
+    """The reference's texture unit stores its filter weights in 1.8 fixed point (CUDA C Programming Guide, "Texture
+    Fetching"; samplers VDBCloud.cpp:123-135, Mie.cpp:8229-8240); this repository's sampler -- kernels and oracle alike --
+    uses the exact float fraction.  libct_oracle_fixed8.so is the restatement with the weights rounded to 1/256: every
+    density differs in its third digit, so nearly every path branches differently somewhere and the two images are two
+    Monte-Carlo estimates with the same random numbers but decorrelated paths.  What can be asked, and is: no bias (window
+    means within the combined confidence interval) and a distance of the order of the noise.  The measured distance is the
+    honest bound on "matches a real OptiX run at a fixed seed": the 1e-3 of the north star is not reachable against ANY
+    implementation whose sampler rounds differently -- it is a property of sharing the arithmetic."""
+    tex = ds.make_procedural_cloud(128)
+    w = h = 256
+    spp = 1024
+    tr = ds.CloudTracer(tex, width=w, height=h)
+    tr.render_accumulate(1, 32)
+    tr.render_accumulate_async(33, spp - 32)
+    mean, m2 = tr.mean(), tr.m2()
+    tr.close()
+    orc = O.Oracle(tex, w, h, fast="fixed8")          # (its own shadow volume, integrated with the same rounded weights)
+    x0, y0, n = 118, 126, 20
+    ref, ref2 = orc.render(spp, window=(x0, y0, x0 + n, y0 + n))
+    got, want = mean[y0:y0 + n, x0:x0 + n, 0].astype(np.float64), ref[y0:y0 + n, x0:x0 + n, 0].astype(np.float64)
+    va = m2[y0:y0 + n, x0:x0 + n, 0].astype(np.float64) / (spp - 1)
+    vb = ref2[y0:y0 + n, x0:x0 + n, 0].astype(np.float64) / (spp - 1)
+    assert want.mean() > 0.3
+    window = np.linalg.norm(got - want) / np.linalg.norm(want)
+    noise = np.sqrt(((va + vb) / spp).sum()) / np.linalg.norm(want)     # relL2 two INDEPENDENT estimates would show
+    per_pixel = np.abs(got - want) / want
+    se = np.sqrt((va.mean() + vb.mean()) / (spp * n * n))
+    print(f"\nMARCH kernel vs oracle with 1.8 fixed-point filter weights, 128^3, {n}x{n} window, {spp} spp: window relL2 {window:.2e} "
+          f"(two independent estimates: {noise:.2e}), median pixel {np.median(per_pixel):.1e}, identical pixels "
+          f"{(got == want).mean():.3f}, window means {got.mean():.5f} / {want.mean():.5f} (s.e. of the difference {se:.1e})")
+    assert abs(got.mean() - want.mean()) <= 1.96 * se            # unbiased against each other
+    assert window <= 1.2 * noise                                  # no further apart than unrelated estimates would be
+    assert window <= 2e-2                                         # measured 7e-3..1e-2 at this size (reported above)

@@ -68,6 +68,11 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a box with one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--group", action="store_true",
+                    help="N > 1 from ONE process: the C ABI's own multi-GPU group (ct_group_*: one handle per device, ncclCommInitAll, one "
+                         "ncclReduce of [mean | M2] per step) instead of one rank per GPU under torch.distributed -- the second, independent "
+                         "N-GPU implementation; run it without torchrun: python bench.py --gpus N --group.  The line carries the same "
+                         "frame_sha256 as the torchrun path's, so the two merged frames can be compared")
     ap.add_argument("--sync-steps", action="store_true",
                     help="wait for every step before the next one is enqueued (no path continuation across launches)")
     return ap.parse_args()
@@ -192,12 +197,26 @@ def progressive_leg(tr, W, H, first, spp=10, updates=100, ahead=0, stop=False):
     return out, first
 
 
-def pmc_traffic(args, S):
-    """roofline.traffic, measured live: two short child runs of this same command under `rocprofv3 --pmc` (FETCH_SIZE
-    and WRITE_SIZE need separate passes: MI355X_MICROARCH.md, HBM section), started BEFORE this process touches the
-    GPU.  Returns bytes across the L2's memory side for one full launch of the timed step and for one
+PMC_PASSES = (
+    # (SQ, TCC and GRBM have their own counter slots -- MI355X_MICROARCH.md "rocprofv3 PMC slots" -- so the scheduler's view rides
+    # along with FETCH_SIZE; FETCH_SIZE and WRITE_SIZE need separate passes)
+    ["FETCH_SIZE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY",
+     "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"],
+    ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+    # the L2's memory-side read requests by destination and size, and their in-flight level (average fabric read latency =
+    # LEVEL / RDREQ): what there is on gfx950 towards "how much of the traffic is HBM" -- see hbm_split in main()
+    ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_32B_sum", "TCC_EA0_RDREQ_GMI_32B_sum", "TCC_EA0_RDREQ_LEVEL_sum"],
+)
+
+
+def pmc_traffic(args, S, estimator=None):
+    """Hardware counters of the timed launch, measured live: three short child runs of this same command under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes: MI355X_MICROARCH.md, HBM section), started BEFORE this
+    process touches the GPU.  Returns bytes across the L2's memory side for one full launch of the timed step and for one
     resume-only launch, FETCH_SIZE doubled (the guide's gfx950 correction, re-calibrated on this kernel's access
-    pattern by tools/fetch_probe.py: 64 B reported per 128-B line) -- or None when the profiler cannot run here."""
+    pattern by tools/fetch_probe.py: 64 B reported per 128-B line), the scheduler's counters of the same launch (lane
+    occupancy, waiting shares, instruction counts) and the memory-side request counters -- or None when the profiler cannot
+    run here."""
     import csv
     import glob
     import shutil
@@ -206,16 +225,18 @@ def pmc_traffic(args, S):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(exe).exists() or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("CT_BENCH_CHILD"):
         return None
+    estimator = args.estimator if estimator is None else estimator
     # (one step of the child is S subframes: one launch when its per-sample scratch fits a slot, else several equal ones)
     child = [sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-delta-leg", "--no-progressive-leg",
              "--no-pmc-traffic", "--volume", str(args.volume), "--width", str(args.width), "--height", str(args.height),
-             "--spp-per-step", str(S), "--mode", str(args.mode), "--estimator", str(args.estimator)]
+             "--spp-per-step", str(S), "--mode", str(args.mode), "--estimator", str(estimator)]
     env = dict(os.environ, CT_BENCH_CHILD="1", TMPDIR="/tmp")
     out = {}
     tmp = tempfile.mkdtemp(prefix="ct_pmc_", dir="/tmp")
     try:
-        for counters in (["FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]):
-            d = os.path.join(tmp, counters[0])
+        child_line = None
+        for k, counters in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, f"pass{k}")
             # (its own process group: on a timeout the profiler AND the child it started are ended, or the child would
             # share the GPU with the timed region)
             proc = subprocess.Popen([exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
@@ -230,7 +251,10 @@ def pmc_traffic(args, S):
             r = subprocess.CompletedProcess(proc.args, proc.returncode, so, se)
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
-                return {"error": f"rocprofv3 --pmc {' '.join(counters)} failed ({r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
+                if k < 2:
+                    return {"error": f"rocprofv3 --pmc {' '.join(counters)} failed ({r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
+                out["_pass2_error"] = f"rocprofv3 --pmc {' '.join(counters)} failed ({r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+                continue
             per = {}
             for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
                 if "render_persistent_kernel" in row["Kernel_Name"] or "render_delta_kernel" in row["Kernel_Name"]:
@@ -250,11 +274,13 @@ def pmc_traffic(args, S):
         if len(fetch) < n_t + 1 or len(write) != len(fetch):
             return {"error": f"unexpected dispatch count {len(fetch)}/{len(write)} for {n_t} timed launches"}
         full = lambda rows: rows[-1 - n_t:-1]
+        per_launch = lambda name: (sum(r[1] for r in full(out[name])) / n_t) if (name in out and len(out[name]) == len(fetch)) else None
         res = {
-            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum: two child runs of this command "
-                      "(1 warm-up + 1 timed step) before the timed process started; FETCH_SIZE x 2 (gfx950: a 128-B request is "
-                      "tallied as 64 B -- MI355X_MICROARCH.md HBM section, re-calibrated by tools/fetch_probe.py) + WRITE_SIZE, "
-                      "KiB -> bytes; Infinity-Cache hits are inside this figure (it is traffic across the L2's memory side)",
+            "source": "rocprofv3 --pmc, three child runs of this command (1 warm-up + 1 timed step) before the timed process started: "
+                      "FETCH_SIZE + the SQ counters / WRITE_SIZE TCC_HIT_sum TCC_MISS_sum / the TCC_EA0_RDREQ_* counters; traffic = FETCH_SIZE x 2 "
+                      "(gfx950: a 128-B request is tallied as 64 B -- MI355X_MICROARCH.md HBM section, re-calibrated by tools/fetch_probe.py, and "
+                      "confirmed by TCC_EA0_RDREQ_DRAM_32B x 32 B in the third run) + WRITE_SIZE, KiB -> bytes; Infinity-Cache hits are inside "
+                      "this figure (it is traffic across the L2's memory side)",
             "full_launch_bytes": (2.0 * sum(r[1] for r in full(fetch)) + sum(r[1] for r in full(write))) * 1024.0 / n_t,
             "resume_launch_bytes": (2.0 * fetch[-1][1] + write[-1][1]) * 1024.0,
             "full_launch_ms_under_pmc": sum(r[2] for r in full(fetch)) / n_t / 1e6,
@@ -265,6 +291,32 @@ def pmc_traffic(args, S):
         if miss and hit and len(miss) == len(fetch):
             res["tcc_miss_per_full_launch"] = sum(r[1] for r in full(miss)) / n_t
             res["l2_hit_rate"] = sum(r[1] for r in full(hit)) / max(sum(r[1] for r in full(hit)) + sum(r[1] for r in full(miss)), 1.0)
+        # the scheduler's view of the same launch (SQ counters count quad-cycles; ratios only)
+        sq = {k: per_launch(k) for k in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU",
+                                         "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE")}
+        if all(v for v in sq.values()):
+            clock_hz = sq["GRBM_GUI_ACTIVE"] / 8.0 / (res["full_launch_ms_under_pmc"] * 1e-3)    # (summed over the 8 XCDs)
+            res["sq"] = {
+                "lane_occupancy": sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"]),
+                "wait_any_over_wave_cycles": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                "wait_inst_any_over_wave_cycles": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
+                "valu_insts_per_launch": sq["SQ_INSTS_VALU"], "salu_insts_per_launch": sq["SQ_INSTS_SALU"], "waves": sq["SQ_WAVES"],
+                "clock_GHz_under_pmc": clock_hz / 1e9,
+                # vector instructions issued per SIMD and cycle against one wave64 instruction per two cycles (SIMD-32)
+                "valu_issue_frac_of_2_cycle_rate": 2.0 * sq["SQ_INSTS_VALU"] / 1024.0 / (sq["GRBM_GUI_ACTIVE"] / 8.0),
+                "definitions": "lane_occupancy = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU); wait_any = share of wave time "
+                               "parked on s_waitcnt; wait_inst_any = share waiting to issue; clock = GRBM_GUI_ACTIVE / 8 / launch time",
+            }
+        ea = {k: per_launch(k) for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_32B_sum", "TCC_EA0_RDREQ_GMI_32B_sum", "TCC_EA0_RDREQ_LEVEL_sum")}
+        if ea["TCC_EA0_RDREQ_sum"]:
+            res["ea"] = {
+                "read_requests_per_launch": ea["TCC_EA0_RDREQ_sum"],
+                "read_bytes_to_local_memory_per_launch": (ea["TCC_EA0_RDREQ_DRAM_32B_sum"] or 0.0) * 32.0,
+                "read_bytes_to_other_sockets_per_launch": (ea["TCC_EA0_RDREQ_GMI_32B_sum"] or 0.0) * 32.0,
+                "avg_read_latency_l2_cycles": (ea["TCC_EA0_RDREQ_LEVEL_sum"] or 0.0) / ea["TCC_EA0_RDREQ_sum"],
+            }
+        elif "_pass2_error" in out:
+            res["ea"] = {"error": out["_pass2_error"]}
         return res
     except Exception as e:  # the figure is optional; the bench line is not
         return {"error": f"{type(e).__name__}: {e}"}
@@ -310,13 +362,54 @@ def measured_ceilings(torch, device):
     per_repeat = (t[12] - t[4]) / 8.0
     if per_repeat > 0:
         out["random_128B_line_GBps_this_run"] = (1 << 25) * 128 / per_repeat / 1e9
+    # ... and the same access shape over WORKING SETS that fit a cache level (ct_debug_fetch_probe_ws: 2^25 lanes, each one
+    # pseudo-random line of the set): the line-fill ceiling of the Infinity Cache (sets up to 256 MiB) beside HBM's
+    by_set = []
+    for mib in (32, 64, 128, 192, 1024, 4096):
+        t = {}
+        for reps in (4, 12, 4, 12):
+            s_out = C.c_uint64(0)
+            t0 = time.perf_counter()
+            if L.ct_debug_fetch_probe_ws(device, 25, mib * 8192, reps, C.byref(s_out)) != 0:
+                return out
+            dt = time.perf_counter() - t0
+            t[reps] = min(t.get(reps, dt), dt)
+        per = (t[12] - t[4]) / 8.0
+        if per > 0:
+            by_set.append({"working_set_MiB": mib, "lines_per_s": (1 << 25) / per, "GBps": (1 << 25) * 128 / per / 1e9})
+    out["random_128B_line_by_working_set_this_run"] = by_set
     return out
 
 
-def delta_leg(ds, tex, W, H, mode, S, steps):
+def working_set_leg(ds, tex, W, H, mode, estimator, spp=64):
+    """Distinct 128-B lines one launch of `spp` subframes reads (ct_debug_track_lines; a handle of its own on the diagnostics
+    kernels, not timed): the kernel's working set, to be held against the 256 MiB of the Infinity Cache."""
+    had = os.environ.get("CT_STATS")
+    os.environ["CT_STATS"] = "1"
+    try:
+        t = ds.CloudTracer(tex, width=W, height=H, mode=mode, estimator=estimator)
+        t.render_accumulate(1, 16)
+        t.track_lines(True)
+        t.render_accumulate(17, spp)
+        out = t.touched_lines()
+        t.close()
+        out["spp_of_the_measured_launch"] = spp
+        out["fits_the_256_MiB_infinity_cache"] = out["touched_MiB"] <= 256.0
+        return out
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        if had is None:
+            os.environ.pop("CT_STATS", None)
+        else:
+            os.environ["CT_STATS"] = had
+
+
+def delta_leg(ds, tex, W, H, mode, S, steps, pmc=None):
     """The same workload with the DELTA estimator (Woodcock tracking, BASELINE.json north_star's algorithm; unbiased,
     not the reference's sampler, so it cannot be the parity path -- DESIGN.md 4.2), reported beside the headline:
-    a second handle, one warm-up step, `steps` enqueued steps between two waits.  Not part of `value`."""
+    a second handle, one warm-up step, `steps` enqueued steps between two waits.  Not part of `value`.  `pmc`: the counters of
+    this kernel's launch from pmc_traffic(..., estimator=1) -- its own roofline block."""
     t = ds.CloudTracer(tex, width=W, height=H, mode=mode, estimator=1)
     t.render_accumulate_async(1, S)
     t.synchronize()
@@ -330,16 +423,90 @@ def delta_leg(ds, tex, W, H, mode, S, steps):
     t.close()
     lookups = (k1["density_lookups"] - k0["density_lookups"]) + (k1["inscatter_lookups"] - k0["inscatter_lookups"])
     paths = k1["paths"] - k0["paths"]
+    launches = max(l1 - l0, 1)
+    sec = (r1 - r0) * 1e-3
     alg = 8 * lookups + 16 * paths   # this kernel issues one fetch per counted lookup: issued bytes == algorithmic bytes
-    return {"estimator": "DELTA (Woodcock tracking over LDS-resident majorant cells)", "value": W * H * S * steps / dt / 1e6,
-            "unit": "Msamples/s", "ms_per_step": dt / steps * 1e3, "kernel": "render_delta_kernel",
-            "avg_launch_ms": (r1 - r0) / max(l1 - l0, 1), "lookups_per_sample": lookups / max(paths, 1),
-            "issued_frac": alg / ((r1 - r0) * 1e-3) / 1e9 / HBM_PEAK_GBS if r1 > r0 else 0.0,
-            "note": "issue-bound, not memory-bound (DESIGN.md 4.2); fabric traffic per launch: profiles/"}
+    out = {"estimator": "DELTA (Woodcock tracking over LDS-resident majorant cells)", "value": W * H * S * steps / dt / 1e6,
+           "unit": "Msamples/s", "ms_per_step": dt / steps * 1e3, "kernel": "render_delta_kernel",
+           "avg_launch_ms": (r1 - r0) / launches, "lookups_per_sample": lookups / max(paths, 1)}
+    roof = {"bound": "hbm", "kernel": "render_delta_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": (r1 - r0) / launches,
+            "useful_frac": alg / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0, "issued_bytes_per_launch": alg / launches}
+    if pmc and "error" not in pmc:
+        traffic = pmc["full_launch_bytes"] + pmc["resume_launch_bytes"] / launches
+        roof.update({
+            "traffic": traffic, "achieved": traffic * launches / sec / 1e9, "frac": traffic * launches / sec / 1e9 / HBM_PEAK_GBS,
+            "traffic_frac": traffic * launches / sec / 1e9 / HBM_PEAK_GBS, "waste_ratio": traffic * launches / alg if alg else None,
+            "l2_hit_rate": pmc.get("l2_hit_rate"), "tcc_miss_per_full_launch": pmc.get("tcc_miss_per_full_launch"),
+            "full_launch_ms_under_pmc": pmc.get("full_launch_ms_under_pmc"), "sq": pmc.get("sq"), "ea": pmc.get("ea"),
+            "traffic_source": pmc["source"],
+            "binding_ceiling": "instruction issue, not line fills: see sq (vector issue at valu_issue_frac_of_2_cycle_rate with the scalar unit "
+                               "busy beside it; waves wait to issue for wait_inst_any of their time) and DESIGN.md 4.2 'Round 4' -- 8 waves per "
+                               "SIMD raise wait_inst_any from 0.30 to 0.47 and lose 6 %, and the twin-brick layout, which moves 32 % fewer bytes, "
+                               "gains 1.6 %",
+        })
+    elif pmc:
+        roof["traffic_error"] = pmc["error"]
+    out["roofline"] = roof
+    return out
+
+
+def frame_sha256(mean, m2):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(mean).tobytes() + np.ascontiguousarray(m2).tobytes()).hexdigest()
+
+
+def group_main(args):
+    """bench.py --gpus N --group: the fixed 1024-spp job on N devices driven by ONE process through ct_group_* (csrc/ct_group.hip:
+    one handle per device, RCCL by ncclCommInitAll, ct_group_merge = one ncclReduce of [mean | M2] per device inside a group call).
+    A step = ct_group_render_accumulate (every shard's batch enqueued, all waited for) + ct_group_merge."""
+    import deepestscatter_amd as ds
+    N = args.gpus
+    W, H = args.width, args.height
+    S = args.spp_per_step if args.spp_per_step > 0 else (512 * N if args.weak else 1024)
+    devices = [0] * N if args.single_device else list(range(N))
+    tex = ds.make_procedural_cloud(args.volume)
+    t_setup = time.perf_counter()
+    g = ds.TracerGroup(tex, devices, ds.SceneParams(width=W, height=H, mode=args.mode, estimator=args.estimator))
+    setup_s = time.perf_counter() - t_setup
+    nxt = 1
+    for _ in range(args.warmup):
+        g.render_accumulate(nxt, S)
+        g.merge()
+        nxt += S
+    t0 = time.perf_counter()
+    merge_s = 0.0
+    for _ in range(args.steps):
+        g.render_accumulate(nxt, S)
+        t1 = time.perf_counter()
+        g.merge()
+        merge_s += time.perf_counter() - t1
+        nxt += S
+    elapsed = time.perf_counter() - t0
+    mean, m2 = g.mean(), g.m2()
+    c = g.counters()
+    out = {
+        "metric": "Msamples/s (rays x spp) at 512^3 vol, 1024^2 frame; HBM GB/s vs roofline",
+        "value": W * H * S * args.steps / elapsed / 1e6, "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.volume}^3 procedural density, {W}x{H}, progressive, {S} spp per step (BASELINE.json configs[3]), one process, "
+                               "ct_group_* below the C ABI", "volume": args.volume, "width": W, "height": H, "spp_per_step": S,
+                   "parallelism": f"pixel-tile shard x{N}, ONE process: ct_group_render_accumulate + ct_group_merge (ncclCommInitAll, one ncclReduce of "
+                                  "[mean | M2] per device per step" + (": devices repeated, merged by copies + an add kernel, no communicator)" if args.single_device else ")"),
+                   "pipelined_steps": False},
+        "multi_gpu": {"implementation": "ct_group (csrc/ct_group.hip)", "devices": devices, "merge_ms_per_step": merge_s / args.steps * 1e3},
+        "roofline": None, "cpu_baseline": None, "setup_s": setup_s,
+        "frame_sha256": frame_sha256(mean, m2), "subframes_in_the_frame": nxt - 1,
+        "counters": c,
+    }
+    g.close()
+    print(json.dumps(out), flush=True)
 
 
 def main():
     args = parse_args()
+    if args.group:
+        return group_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -351,9 +518,11 @@ def main():
     W, H = args.width, args.height
     S = args.spp_per_step if args.spp_per_step > 0 else (512 * world if args.weak else 1024)
     # roofline.traffic from the hardware counters, before anything here touches the GPU (child processes)
-    pmc = None
+    pmc, pmc_delta = None, None
     if world == 1 and not args.no_pmc_traffic and not args.simple_kernel:
         pmc = pmc_traffic(args, S)
+        if args.estimator == 0 and not args.no_delta_leg:
+            pmc_delta = pmc_traffic(args, S, estimator=1)   # the DELTA leg's own roofline block
 
     import torch
     import torch.distributed as dist
@@ -516,20 +685,25 @@ def main():
     miss_per_launch = pmc_extra.get("tcc_miss_per_full_launch")
     lines_per_s = miss_per_launch * launches / sec if (miss_per_launch and sec > 0) else None
     probe_lines_per_s = (here.get("random_128B_line_GBps_this_run") or MEASURED_RANDOM_LINE_GBS) * 1e9 / 128.0
-    resident_lanes = tr.launch_lanes() if hasattr(tr, "launch_lanes") else 256 * 24 * 64
-    lane_occ = 0.41   # SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), profiles/r02r
+    resident_lanes = 64.0 * pmc["sq"]["waves"] if (pmc and "error" not in pmc and pmc.get("sq")) else None   # (persistent kernel: every wave resident)
+    lane_occ = (pmc or {}).get("sq", {}).get("lane_occupancy") if pmc and "error" not in pmc else None   # measured in this run, or absent
     hbm_miss_ns, mall_hit_ns = 900 / 2.4, 545 / 2.4     # MI355X_MICROARCH.md, idle chip, one lane
+    # the probe's rate by working set: which level do this kernel's lines come from?  (working_set: one launch's distinct lines)
+    by_set = {p["working_set_MiB"]: p["lines_per_s"] for p in here.get("random_128B_line_by_working_set_this_run", [])}
     latency_model = {
         "lines_per_s": lines_per_s, "probe_random_lines_per_s": probe_lines_per_s,
         "frac_of_line_fill_rate": lines_per_s / probe_lines_per_s if lines_per_s else None,
+        "probe_random_lines_per_s_by_working_set_MiB": by_set or None,
+        "frac_of_line_fill_rate_of_a_128_MiB_set": lines_per_s / by_set[128] if (lines_per_s and by_set.get(128)) else None,
         "resident_lanes": resident_lanes, "lane_occupancy": lane_occ,
+        "lane_occupancy_source": "SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) of the timed launch, rocprofv3 --pmc child run of this command" if lane_occ else
+                                 "not measured in this run (no profiler, N > 1 or --no-pmc-traffic)",
         "miss_latency_ns_idle_chip": {"infinity_cache_hit": mall_hit_ns, "hbm": hbm_miss_ns},
-        "littles_law_ceiling_lines_per_s": resident_lanes * lane_occ / (hbm_miss_ns * 1e-9),
-        "frac_of_littles_law_ceiling": lines_per_s / (resident_lanes * lane_occ / (hbm_miss_ns * 1e-9)) if lines_per_s else None,
-        "reading": "the kernel fills lines at frac_of_line_fill_rate of what the fabric delivers to a pure random-line gather and at "
-                   "frac_of_littles_law_ceiling of what its resident lanes could keep in flight if they did nothing but wait for "
-                   "misses: it is near the fabric's line-fill rate, not near its own concurrency limit -- and in between fetches its "
-                   "lanes compute at 41 % occupancy, which is why removing misses buys little (DESIGN.md 4.3)",
+        "littles_law_ceiling_lines_per_s": resident_lanes * lane_occ / (hbm_miss_ns * 1e-9) if (resident_lanes and lane_occ) else None,
+        "frac_of_littles_law_ceiling": lines_per_s / (resident_lanes * lane_occ / (hbm_miss_ns * 1e-9)) if (lines_per_s and resident_lanes and lane_occ) else None,
+        "reading": "the kernel fills lines at frac_of_line_fill_rate of what the fabric delivers to a pure random-line gather over 4 GiB "
+                   "(every line from HBM) and at frac_of_littles_law_ceiling of what its resident lanes could keep in flight if they did "
+                   "nothing but wait for misses: it is near the fabric's line-fill rate, not near its own concurrency limit (DESIGN.md 4.3)",
     }
     roofline = {
         "bound": "hbm",
@@ -596,6 +770,15 @@ def main():
     if multi:
         out["multi_gpu"] = multi
         out["rccl_ranks"] = multi["rccl_ranks"]
+    if rank == 0:
+        # the merged frame the timed steps produced ([mean | M2] after `subframes_in_the_frame` subframes): equal, bit for bit, to
+        # the frame of `bench.py --gpus N --group` with the same --steps / --warmup, and to the N = 1 frame
+        if world > 1:
+            fm = st.merged.cpu().numpy()
+            out["frame_sha256"] = frame_sha256(fm[0], fm[1])
+        else:
+            out["frame_sha256"] = frame_sha256(tr.mean(), tr.m2())
+        out["subframes_in_the_frame"] = nxt - 1
     if rank == 0 and world == 1 and not args.simple_kernel and not args.no_progressive_leg and not args.sync_steps:
         prog, nxt = progressive_leg(tr, W, H, nxt)
         prog["fraction_of_headline"] = prog["value"] / value
@@ -610,7 +793,7 @@ def main():
         prog["reference_loop_every_call_waited_for"] = waited
         out["progressive_10spp"] = prog
     if rank == 0 and world == 1 and args.estimator == 0 and not args.simple_kernel and not args.no_delta_leg:
-        out["delta_estimator"] = delta_leg(ds, tex, W, H, args.mode, S, max(args.steps, 1))
+        out["delta_estimator"] = delta_leg(ds, tex, W, H, args.mode, S, max(args.steps, 1), pmc_delta)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ins = tr.inscatter()
         out["cpu_baseline"] = cpu_baseline(ds, tex, ins, W, H, args.mode, args.cpu_seconds)

@@ -330,20 +330,43 @@ class CloudTracer:
         a = np.ascontiguousarray(data, np.float32)
         check(self.L.ct_upload(self.h, which, _p(a), a.nbytes), self.h)
 
+    @staticmethod
+    def _state_path(path):
+        """np.savez appends '.npz' to a name without it; np.load does not: both sides use the same file name."""
+        from pathlib import Path
+        p = Path(path)
+        return p if p.suffix == ".npz" else p.with_name(p.name + ".npz")
+
     def save_state(self, path):
-        """(mean, M2, subframe count) -> .npz: everything a progressive render needs to continue exactly."""
+        """(mean, M2, subframe count) -> .npz: everything a progressive render needs to continue exactly.  The count is that of
+        the samples IN the buffers: with ct_set_stop_when_converged the running mean freezes at the reference's stopping count
+        while the host goes on submitting (and ct_subframes goes on counting) -- then the frozen count is what is saved."""
         n = C.c_uint32(0)
         check(self.L.ct_subframes(self.h, C.byref(n)), self.h)
-        mean, m2 = self.mean(), self.m2()          # (these wait: the count below is what the buffers hold)
-        np.savez(path, mean=mean, m2=m2, subframes=np.uint32(n.value))
+        mean, m2 = self.mean(), self.m2()          # (these wait: the counts read here and below are what the buffers hold)
+        frozen_at = self.converged_at()[0]
+        count = frozen_at if frozen_at else n.value
+        np.savez(self._state_path(path), mean=mean, m2=m2, subframes=np.uint32(count))
 
     def load_state(self, path) -> int:
-        with np.load(path) as z:
+        """The reverse: the handle continues with subframe `count + 1`.  A handle whose image had frozen is released (ct_upload
+        and ct_set_subframes clear the flag: the image they describe is a new one)."""
+        with np.load(self._state_path(path)) as z:
             self.upload(CT_BUF_MEAN, z["mean"])
             self.upload(CT_BUF_M2, z["m2"])
             n = int(z["subframes"])
         self.set_subframes(n)
         return n
+
+    def track_lines(self, enable: bool = True):
+        """ct_debug_track_lines: record which 128-B lines of the density and shadow arrays the launches read (CT_STATS=1)."""
+        check(self.L.ct_debug_track_lines(self.h, 1 if enable else 0), self.h)
+
+    def touched_lines(self, clear: bool = False) -> dict:
+        out = (C.c_uint64 * 4)()
+        check(self.L.ct_debug_touched_lines(self.h, out, 1 if clear else 0), self.h)
+        return {"density_lines_touched": int(out[0]), "shadow_lines_touched": int(out[1]), "density_lines": int(out[2]), "shadow_lines": int(out[3]),
+                "touched_MiB": (int(out[0]) + int(out[1])) * 128 / 2 ** 20}
 
     def mean(self):
         return self.download(CT_BUF_MEAN)

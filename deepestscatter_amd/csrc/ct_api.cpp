@@ -23,7 +23,37 @@
 
 using namespace ct;
 
+// ---- tuning knobs ----------------------------------------------------------------------------------------------------------
+// Every environment variable the library reads, copied ONCE per ct_create into the handle (DESIGN.md 4.4 lists them with
+// what they do and what was measured).  Knobs choose schedules, scratch sizes, layouts and diagnostics; none changes a
+// result (tests/test_gpu_parity.py: the knob test).  get() returns the variable's text as it was at ct_create, or NULL.
+struct Knob {
+    bool is_set = false;
+    std::string text;
+    const char *get() const { return is_set ? text.c_str() : nullptr; }
+    explicit operator bool() const { return is_set; }
+};
+#define CT_KNOBS(X) X(BURST_IDLE) X(BURST_MARCH_MIN) X(BURST_SCATTER) X(CHUNK_INTERLEAVE) X(CHUNK_MORTON) X(CONTINUATION) X(DEBUG_INVARIANTS) X(DELTA_NEE) X(EXCHANGE) X(HAND_ON_JOBS) X(HINT_PERIOD) X(JOB_MAX) X(JOB_WORK) X(MARCH_BURST) X(MAX_AGE) X(NEE_CACHE) X(NO_ADVANCE) X(POINT_BLOCKS_PER_CU) X(POINT_ORDER) X(REGEN_MIN) X(RENDER_AHEAD) X(SCATTER_MIN) X(SCATTER_RATIO) X(SCRATCH_GIB) X(SCRATCH_MIB) X(SERPENTINE) X(SHARED_DEPTH) X(SPARSE) X(STATS) X(TAIL_BURST) X(TILE_ORDER) X(TIMELINE) X(TRACE) X(TUNE_SUBFRAMES) X(XCD_QUEUES) X(XCD_QUEUES_UNTUNED) X(XCD_REGIONS) X(BLOCKS_PER_CU)
+struct CtTuning {
+#define X(name) Knob name;
+    CT_KNOBS(X)
+#undef X
+    static CtTuning from_env()
+    {
+        CtTuning t;
+#define X(name)                                  \
+    if (const char *e = getenv("CT_" #name)) {   \
+        t.name.is_set = true;                    \
+        t.name.text = e;                         \
+    }
+        CT_KNOBS(X)
+#undef X
+        return t;
+    }
+};
+
 struct CtHandle_ {
+    CtTuning tune;         // the environment's knobs as they were at ct_create
     CtScene scene{};       // as given (host pointers are NOT retained)
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -113,6 +143,8 @@ struct CtHandle_ {
     uint32_t *d_pixels = nullptr;     // this shard's box-hitting pixels, padded to groups of 64
     uint8_t *d_hit = nullptr, *hit_host = nullptr;   // per pixel: the primary ray hits the box (device; pinned host copy)
     uint32_t *d_cost = nullptr;       // measured per group: [0,n) sum of path costs, [n,2n) deepest path
+    uint32_t *d_touched[2] = { nullptr, nullptr };   // ct_debug_track_lines: one bit per line of the density / shadow arrays
+    size_t touched_lines[2] = { 0, 0 };
     unsigned long long *d_timeline = nullptr;   // CT_TIMELINE=1: [start, end] of every wave of the last enqueued estimator launch (MARCH)
     uint2 *d_cost_plane = nullptr;    // ... as the cost-measuring launch leaves them, per sample (BatchArgs::cost)
     size_t cost_plane_capacity = 0;
@@ -220,7 +252,7 @@ struct TracePhase {
     const char *name;
     std::chrono::steady_clock::time_point t0;
     bool on;
-    explicit TracePhase(const char *n) : name(n), t0(std::chrono::steady_clock::now()), on(getenv("CT_TRACE") != nullptr) {}
+    TracePhase(CtHandle h, const char *n);
     ~TracePhase()
     {
         if (on) {
@@ -229,6 +261,8 @@ struct TracePhase {
         }
     }
 };
+
+inline TracePhase::TracePhase(CtHandle h, const char *n) : name(n), t0(std::chrono::steady_clock::now()), on(h && h->tune.TRACE) {}
 
 static int flush(CtHandle h);
 static int check_invariants(CtHandle h);
@@ -364,7 +398,7 @@ static void release(CtHandle h)
     if (h->stream) {
         hipStreamSynchronize(h->stream);
     }
-    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_tbricks, h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
+    void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_tbricks, h->d_touched[0], h->d_touched[1], h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_group_rank, h->d_group_order, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->d_hit, h->d_cost_plane, h->d_timeline, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
     for (void *p : ptrs) {
@@ -416,6 +450,7 @@ static int create_impl(const CtScene *s, CtHandle h)
     h->scene = *s;
     h->device = s->device;
     h->volume_bytes = texels;
+    h->tune = CtTuning::from_env();
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -431,18 +466,26 @@ static int create_impl(const CtScene *s, CtHandle h)
     for (auto &e : h->ev) {
         HIPCHK(h, hipEventCreate(&e));
     }
-    h->shape = persistent_shape(s->device, s->estimator == CT_EST_DELTA);
-    if (const char *e = getenv("CT_DEBUG_INVARIANTS")) {
+    h->shape = persistent_shape(s->device, s->estimator == CT_EST_DELTA, h->tune.BLOCKS_PER_CU ? atoi(h->tune.BLOCKS_PER_CU.get()) : 0);
+    if (const char *e = h->tune.DEBUG_INVARIANTS.get()) {
         h->debug_invariants = atoi(e) != 0;
     }
-    h->shape.stats = getenv("CT_STATS") != nullptr || h->debug_invariants;
-    if (const char *e = getenv("CT_EXCHANGE")) {
+    h->shape.stats = h->tune.STATS.get() != nullptr || h->debug_invariants;
+    if (const char *e = h->tune.EXCHANGE.get()) {
         h->exchange = s->estimator == CT_EST_DELTA ? std::min(2, std::max(0, atoi(e))) : 0;
     }
+#ifdef CT_EXPERIMENTS
     if (h->exchange) {
         h->xshape = h->exchange == 2 ? wave_exchange_shape(s->device) : exchange_shape(s->device);
         h->xshape.stats = h->shape.stats;
     }
+#else
+    if (h->exchange) {
+        // the product's library holds the product's kernels only; the measured-and-rejected ones live in the experiments build
+        return fail(h, CT_E_INVAL, "CT_EXCHANGE needs the experiments build (python -m deepestscatter_amd.build --variant exp; "
+                                   "CT_LIBRARY=libcloudtrace_exp.so)");
+    }
+#endif
 
     // ---- uniforms: VDBCloud::setupVolumeVariables (VDBCloud.cpp:98-111), Sun::init (Sun.cpp:13-18)
     DevScene &d = h->dev;
@@ -523,61 +566,69 @@ static int create_impl(const CtScene *s, CtHandle h)
             d.regen_min = 16;
         }
     }
-    if (const char *e = getenv("CT_JOB_MAX")) {
+    if (const char *e = h->tune.JOB_MAX.get()) {
         h->job_max = (uint32_t)std::min(4096, std::max(1, atoi(e)));
     }
     if (s->estimator == CT_EST_DELTA) {
         h->job_work = 48.f;     // (its cost unit is a bounce; 16 measured 0.4 % slower there)
-        d.delta_nee = 0u;
-        if (const char *e = getenv("CT_DELTA_NEE")) {   // render_delta_kernel<.., NEE>: where a collision's two lookups come from
+        // measured at 512^3 / 1024^2 (profiles/r04b, r04c): 0 -> 5020 Msamples/s, 1 -> 5125 (+2.1 %: 2.8 % fewer vector
+        // instructions, the NEE miss off the bounce's critical path), 2 -> 5100 (+1.6 % although the launch moves 32 % fewer
+        // bytes: the kernel is bound by instruction issue, not by line fills -- DESIGN.md 4.2 "Round 4")
+        d.delta_nee = 1u;
+        // ... and at 1024^3 / 2048^2, where nine fetches in ten miss L2 and the volume is four times the Infinity Cache, the
+        // twin bricks win: 0 -> 3841, 1 -> 3914, 2 -> 4562 Msamples/s (+19 %; profiles/r04d)
+        if ((uint64_t)nx * ny * nz >= 768ull * 768ull * 768ull) {
+            d.delta_nee = 2u;
+        }
+        if (const char *e = h->tune.DELTA_NEE.get()) {   // render_delta_kernel<.., NEE>: where a collision's two lookups come from
             d.delta_nee = (uint32_t)std::min(2, std::max(0, atoi(e)));
         }
     }
-    if (const char *e = getenv("CT_JOB_WORK")) {
+    if (const char *e = h->tune.JOB_WORK.get()) {
         h->job_work = (float)std::max(1.0, atof(e));
     }
-    if (const char *e = getenv("CT_NO_ADVANCE")) {
+    if (const char *e = h->tune.NO_ADVANCE.get()) {
         h->no_advance = atoi(e) != 0;
     }
-    if (const char *e = getenv("CT_XCD_QUEUES")) {
+    if (const char *e = h->tune.XCD_QUEUES.get()) {
         h->queues_enabled = atoi(e) != 0;
     }
     d.burst_march_min = 1;
-    if (const char *e = getenv("CT_BURST_MARCH_MIN")) {
+    if (const char *e = h->tune.BURST_MARCH_MIN.get()) {
         d.burst_march_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     }
     d.hint_period = 64;
-    if (const char *e = getenv("CT_HINT_PERIOD")) {
+    if (const char *e = h->tune.HINT_PERIOD.get()) {
         const int v = atoi(e);
         d.hint_period = (v > 0 && (v & (v - 1)) == 0) ? (uint32_t)v : 0u;
     }
     d.tail_burst = 8;
-    if (const char *e = getenv("CT_TAIL_BURST")) {
+    if (const char *e = h->tune.TAIL_BURST.get()) {
         d.tail_burst = (uint32_t)std::min(1024, std::max(1, atoi(e)));
     }
-    if (const char *e = getenv("CT_XCD_REGIONS")) {
+    if (const char *e = h->tune.XCD_REGIONS.get()) {
         h->regions = (uint32_t)std::min(65536, std::max(1, atoi(e)));
     }
-    if (const char *e = getenv("CT_SHARED_DEPTH")) {
+    if (const char *e = h->tune.SHARED_DEPTH.get()) {
         h->shared_depth = (float)atof(e);
     }
-    if (const char *e = getenv("CT_MARCH_BURST")) {
+    if (const char *e = h->tune.MARCH_BURST.get()) {
         d.march_burst = (uint32_t)std::min(1024, std::max(1, atoi(e)));
     }
-    if (const char *e = getenv("CT_BURST_SCATTER")) {
+    if (const char *e = h->tune.BURST_SCATTER.get()) {
         d.burst_scatter = (uint32_t)std::min(65, std::max(1, atoi(e)));
     }
-    if (const char *e = getenv("CT_BURST_IDLE")) {
+    if (const char *e = h->tune.BURST_IDLE.get()) {
         d.burst_idle = (uint32_t)std::min(65, std::max(1, atoi(e)));
     }
-    if (const char *e = getenv("CT_SCATTER_MIN")) {
+    if (const char *e = h->tune.SCATTER_MIN.get()) {
         d.scatter_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     }
     // tuning knobs for experiments (schedule only; results never change)
-    if (const char *e = getenv("CT_REGEN_MIN")) {
+    if (const char *e = h->tune.REGEN_MIN.get()) {
         d.regen_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     }
-    if (const char *e = getenv("CT_SCATTER_RATIO")) { // "num/den"
+    if (const char *e = h->tune.SCATTER_RATIO.get()) { // "num/den"
         unsigned a = 1, b = 1;
         if (sscanf(e, "%u/%u", &a, &b) == 2 && b > 0 && a < 1000 && b < 1000) {
             d.scatter_num = a;
@@ -601,10 +652,10 @@ static int create_impl(const CtScene *s, CtHandle h)
     }
     d.brick_bias = bbias;
     d.nee_cache = (bgx * bgy * bgz < (1ll << 25)) ? 1u : 0u;
-    if (const char *e = getenv("CT_NEE_CACHE")) {
+    if (const char *e = h->tune.NEE_CACHE.get()) {
         d.nee_cache = (atoi(e) != 0 && d.nee_cache) ? 1u : 0u;
     }
-    if (const char *e = getenv("CT_POINT_ORDER")) {
+    if (const char *e = h->tune.POINT_ORDER.get()) {
         h->point_order = atoi(e) != 0;
     }
     d.brick_gx = (int32_t)bgx;
@@ -773,7 +824,7 @@ static int create_impl(const CtScene *s, CtHandle h)
         // are few line fills to save.  With 288 GB of HBM the dense array is the faster choice; this is the option for
         // when capacity matters.
         bool sparse = (s->flags & CT_FLAG_SPARSE_BRICKS) != 0;
-        if (const char *env = getenv("CT_SPARSE")) {
+        if (const char *env = h->tune.SPARSE.get()) {
             sparse = atoi(env) != 0;
         }
         int src = CT_OK;
@@ -870,36 +921,36 @@ static int create_impl(const CtScene *s, CtHandle h)
     h->cont_capacity = (size_t)h->shape.blocks * h->shape.threads;
     HIPCHK(h, hipEventCreate(&h->ev_flush0));
     HIPCHK(h, hipEventCreate(&h->ev_flush1));
-    if (const char *e = getenv("CT_CONTINUATION")) {
+    if (const char *e = h->tune.CONTINUATION.get()) {
         h->continuation = atoi(e) != 0;
     }
     if (h->exchange) {
         h->continuation = false;   // (the exchange kernels run every path to its end)
     }
-    if (const char *e = getenv("CT_CHUNK_INTERLEAVE")) {
+    if (const char *e = h->tune.CHUNK_INTERLEAVE.get()) {
         h->chunk_interleave = atoi(e) != 0;
     }
-    if (const char *e = getenv("CT_TILE_ORDER")) {
+    if (const char *e = h->tune.TILE_ORDER.get()) {
         h->tile_hilbert = strcmp(e, "hilbert") == 0;
     }
-    if (const char *e = getenv("CT_CHUNK_MORTON")) {
+    if (const char *e = h->tune.CHUNK_MORTON.get()) {
         h->chunk_morton = atoi(e) != 0;
     }
-    if (const char *e = getenv("CT_SERPENTINE")) {
+    if (const char *e = h->tune.SERPENTINE.get()) {
         h->serpentine = atoi(e) != 0;
     }
-    if (const char *e = getenv("CT_HAND_ON_JOBS")) {
+    if (const char *e = h->tune.HAND_ON_JOBS.get()) {
         h->hand_on_jobs = atoi(e) != 0;
     }
-    if (const char *e = getenv("CT_MAX_AGE")) {
+    if (const char *e = h->tune.MAX_AGE.get()) {
         h->max_age_override = std::min(CtHandle_::kMaxRegions - 1, std::max(0, atoi(e)));
     }
-    if (getenv("CT_TIMELINE")) {
+    if (h->tune.TIMELINE.get()) {
         const size_t waves = (size_t)h->shape.blocks * h->shape.threads / 64u;
         HIPCHK(h, dmalloc(&h->d_timeline, 4 * waves));
         HIPCHK(h, hipMemsetAsync(h->d_timeline, 0, 4 * waves * sizeof(unsigned long long), h->stream));
     }
-    if (const char *e = getenv("CT_RENDER_AHEAD")) {
+    if (const char *e = h->tune.RENDER_AHEAD.get()) {
         h->ahead = (uint32_t)std::min(65535, std::max(0, atoi(e)));
     }
     HIPCHK(h, dmalloc(&h->d_cont_total, 1));
@@ -1046,7 +1097,7 @@ extern "C" int ct_set_camera(CtHandle h, const float eye[3], const float U[3], c
 // tile-Morton order, cut into groups of 64 (one wave's worth).
 static int rebuild_queue(CtHandle h)
 {
-    TracePhase trace("rebuild_queue");
+    TracePhase trace(h, "rebuild_queue");
     const uint32_t W = h->scene.width, H = h->scene.height;
     const size_t pixels = (size_t)W * H;
     HIPCHK(h, launch_primary_rays(h->dev, h->d_primary, h->stream));
@@ -1170,7 +1221,7 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
     if (h->jobs_S >= S && h->jobs_brief == short_batch(h, S) && h->chunk_groups == chunk_groups) {
         return CT_OK; // a list for a larger batch serves a smaller one (the kernel clips the jobs)
     }
-    TracePhase trace("build_jobs");
+    TracePhase trace(h, "build_jobs");
     if (h->order_tuned) {
         S = std::max(S, h->jobs_hint);   // (the cost-measuring launch gets a list of its own: one-subframe jobs, its few subframes only)
     }
@@ -1182,11 +1233,11 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
     const bool brief = short_batch(h, S);
     // (per-XCD queues are cut at equal shares of the MEASURED cost: before anything is measured they would be equal shares of
     // pixels, and the XCD that got the cloud's body would finish long after the others)
-    const bool queues = (h->queues_enabled || (brief && !getenv("CT_XCD_QUEUES"))) && !(h->scene.flags & CT_FLAG_SIMPLE_KERNEL) &&
-                        (h->order_tuned || getenv("CT_XCD_QUEUES_UNTUNED"));
+    const bool queues = (h->queues_enabled || (brief && !h->tune.XCD_QUEUES.get())) && !(h->scene.flags & CT_FLAG_SIMPLE_KERNEL) &&
+                        (h->order_tuned || h->tune.XCD_QUEUES_UNTUNED.get());
     const uint32_t nq = (queues && h->n_groups >= (uint32_t)kQueues) ? (uint32_t)kQueues : 1u;
-    const uint32_t regions_wanted = (brief && !h->queues_enabled && !getenv("CT_XCD_REGIONS")) ? 16u : h->regions;
-    const float job_work = (brief && !getenv("CT_JOB_WORK")) ? 4.f : h->job_work;
+    const uint32_t regions_wanted = (brief && !h->queues_enabled && !h->tune.XCD_REGIONS.get()) ? 16u : h->regions;
+    const float job_work = (brief && !h->tune.JOB_WORK.get()) ? 4.f : h->job_work;
     // Groups whose paths are deep (mean cost >= shared_depth bounces) go to the shared queue.
     const float shared_cost = h->shared_depth * unit;
     std::vector<uint8_t> queue_of(h->n_groups, 0);
@@ -1302,7 +1353,7 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
     for (int x = 0; x <= kQueues + 1; x++) {
         h->q_begin[x] = h->chunk_q_begin[0][x];
     }
-    if (getenv("CT_STATS")) {
+    if (h->tune.STATS.get()) {
         fprintf(stderr, "[cloudtrace] job queues (S=%u, %u chunk(s) of %u groups):", S, n_chunks, chunk_groups);
         for (int x = 0; x <= kQueues; x++) {
             fprintf(stderr, " q%d weight %.0f;", x, q_weight[x]);
@@ -1354,7 +1405,7 @@ static int build_jobs(CtHandle h, uint32_t S, uint32_t chunk_groups)
 // the job lengths only change the schedule, never a result.
 static int tune_order(CtHandle h, uint32_t measured_subframes)
 {
-    TracePhase trace("tune_order");
+    TracePhase trace(h, "tune_order");
     h->order_tuned = true;
     if (h->n_groups < 2 || measured_subframes == 0) {
         return CT_OK;
@@ -1390,7 +1441,7 @@ static int tune_order(CtHandle h, uint32_t measured_subframes)
         }
         return log2_class(cost[a]) > log2_class(cost[b]);
     });
-    if (getenv("CT_STATS")) {
+    if (h->tune.STATS.get()) {
         // share of the measured cost by class of the deepest path seen
         std::vector<double> share(34, 0.0);
         std::vector<uint32_t> count(34, 0);
@@ -1447,10 +1498,10 @@ static uint64_t scratch_slot_bytes(CtHandle h)
     // frame is then ONE launch, 14 GB, instead of two of 512 -- a launch costs a few ms besides its samples -- and 28 GB of
     // scratch are a tenth of this GPU's memory.  Allocated as needed; a device that cannot give that much gets less (below).
     uint64_t slot_bytes = 16ull << 30;
-    if (const char *e = getenv("CT_SCRATCH_GIB")) {
+    if (const char *e = h->tune.SCRATCH_GIB.get()) {
         slot_bytes = (uint64_t)std::min(64, std::max(1, atoi(e))) << 30;
     }
-    if (const char *e = getenv("CT_SCRATCH_MIB")) {   // (tests: chunks of a few pixel groups on small frames)
+    if (const char *e = h->tune.SCRATCH_MIB.get()) {   // (tests: chunks of a few pixel groups on small frames)
         slot_bytes = (uint64_t)std::min(65536, std::max(1, atoi(e))) << 20;
     }
     return slot_bytes;
@@ -1544,7 +1595,7 @@ static int collect(CtHandle h, CtHandle_::Slot &sl)
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, sl.ev_start, sl.ev_done));
     h->render_ms += ms;
-    if (getenv("CT_TRACE")) {
+    if (h->tune.TRACE.get()) {
         uint32_t cnt[3] = { 0, 0, 0 };
         hipMemcpy(cnt, h->d_cont_count, sizeof cnt, hipMemcpyDeviceToHost);
         fprintf(stderr, "[cloudtrace] estimator launch %.2f ms (suspended paths per buffer now: %u %u, cursor %u)\n", ms,
@@ -1663,15 +1714,22 @@ static void discard_ahead(CtHandle h)
 static int launch_estimator(CtHandle h, const BatchArgs &ba)
 {
     DevScene sc = h->dev;
-    if (ba.S != 0 && short_batch(h, ba.S) && !getenv("CT_REGEN_MIN")) {
+    if (ba.S != 0 && short_batch(h, ba.S) && !h->tune.REGEN_MIN.get()) {
         sc.regen_min = 16;   // (see short_batch)
     }
+    bool launched = false;
+#ifdef CT_EXPERIMENTS
     if (h->exchange && !ba.cost && !ba.cont_in && !ba.cont_out && h->scene.estimator == CT_EST_DELTA) {
         if (h->exchange == 2) {
             HIPCHK(h, launch_render_delta_w(sc, ba, h->xshape, h->stream));
         } else {
             HIPCHK(h, launch_render_delta_x(sc, ba, h->xshape, h->stream));
         }
+        launched = true;
+    }
+#endif
+    if (launched) {
+        // (an experiments-build kernel rendered the batch)
     } else if (h->scene.estimator == CT_EST_DELTA) {
         HIPCHK(h, launch_render_delta(sc, ba, h->shape, h->stream));
     } else {
@@ -1732,6 +1790,8 @@ static int submit_batch(CtHandle h, int slot, float4 *dense_frames, uint32_t fir
     ba.counters = h->d_counters;
     ba.stats = h->d_counters + kCounterCount + 1;
     ba.timeline = h->d_timeline;
+    ba.touched_density = h->d_touched[0];
+    ba.touched_shadow = h->d_touched[1];
     if (suspend && short_batch(h, S) && h->serpentine) {
         ba.reverse = (uint32_t)(h->launch_no & 1u);
     }
@@ -1905,7 +1965,7 @@ static int flush(CtHandle h)
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev_flush0, h->ev_flush1));
         h->render_ms += ms; // the launch that only resumes belongs to the estimator's time
-        if (getenv("CT_TRACE")) {
+        if (h->tune.TRACE.get()) {
             fprintf(stderr, "[cloudtrace] resume-only launch %.2f ms\n", ms);
         }
     }
@@ -2045,13 +2105,10 @@ constexpr uint32_t kTuneSubframes = 16;
 // launch booking what they have cost so far, times 1..4 -- 18 ms instead of 26-48.  The order made from paths cut short is worse:
 // the launches that follow take 352-359 ms per 1024 subframes instead of 349 for as long as the pose lasts, and the first image of
 // a pose needs its longest path either way.  Removed.)
-static uint32_t tune_subframes()
+static uint32_t tune_subframes(CtHandle h)
 {
-    static const uint32_t n = [] {
-        const char *e = getenv("CT_TUNE_SUBFRAMES");   // (A/B: how short may the cost-measuring launch be?)
-        return e ? (uint32_t)std::min(1024, std::max(1, atoi(e))) : kTuneSubframes;
-    }();
-    return n;
+    const char *e = h->tune.TUNE_SUBFRAMES.get();   // (A/B: how short may the cost-measuring launch be?)
+    return e ? (uint32_t)std::min(1024, std::max(1, atoi(e))) : kTuneSubframes;
 }
 
 static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32_t count, bool wait)
@@ -2142,10 +2199,10 @@ static int render_accumulate_impl(CtHandle h, uint32_t first_subframe_id, uint32
             // order): it is kept short, waited for, then the order is set
             // (a call of a display update's size is the cost-measuring launch as a whole: 10 subframes waited for cost 27 ms, 8 of
             // them 26 and the other 2 a launch and a flush of their own)
-            S = std::min(S, h->jobs_hint <= tune_subframes() + tune_subframes() / 2u ? std::max(h->jobs_hint, 1u) : tune_subframes());
+            S = std::min(S, h->jobs_hint <= tune_subframes(h) + tune_subframes(h) / 2u ? std::max(h->jobs_hint, 1u) : tune_subframes(h));
             rc = run_batch(h, nullptr, first_subframe_id + done, S, true);
         } else {
-            const bool trace = getenv("CT_TRACE") != nullptr;
+            const bool trace = h->tune.TRACE.get() != nullptr;
             const auto t0 = std::chrono::steady_clock::now();
             rc = prepare_batches(h, S);
             // several chunks: they are enqueued like batches (paths pass from chunk to chunk) and a waited-for call waits at the end
@@ -2338,7 +2395,7 @@ extern "C" int ct_point_radiance_launch(CtHandle h, CtPointRadianceTask *tasks_h
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) {
             const int per_cu = std::max(1, shape.blocks / cus);
             int share = std::max(1, per_cu / std::max(1, in_flight.mine));
-            if (const char *e = getenv("CT_POINT_BLOCKS_PER_CU")) {   // (A/B)
+            if (const char *e = h->tune.POINT_BLOCKS_PER_CU.get()) {   // (A/B)
                 share = std::min(per_cu, std::max(1, atoi(e)));
             }
             shape.blocks = share * cus;
@@ -2587,7 +2644,7 @@ extern "C" int ct_reset(CtHandle h)
 static int tonemap_impl(CtHandle h, const float4 *mean, float exposure, uint8_t *rgba_host, float *avg_luminance_out)
 {
     HIPCHK(h, launch_reinhard(mean, h->scene.width, h->scene.height, exposure, h->d_colsum, h->d_avg,
-                              h->d_screen, &h->reinhard_generation, h->stream));
+                              h->d_screen, &h->reinhard_generation, h->device, h->stream));
     if (rgba_host) {
         HIPCHK(h, hipMemcpyAsync(rgba_host, h->d_screen, (size_t)h->scene.width * h->scene.height * sizeof(uchar4),
                                  hipMemcpyDeviceToHost, h->stream));
@@ -2610,7 +2667,7 @@ extern "C" int ct_tonemap_async(CtHandle h, float exposure)
     NEED_NOFLUSH(h);
     // (behind whatever is enqueued: the running mean of the batches whose accumulate kernels precede it on the stream)
     HIPCHK(h, launch_reinhard(h->d_mean, h->scene.width, h->scene.height, exposure, h->d_colsum, h->d_avg, h->d_screen, &h->reinhard_generation,
-                              h->stream));
+                              h->device, h->stream));
     return CT_OK;
 }
 
@@ -2713,6 +2770,17 @@ extern "C" int ct_download(CtHandle h, int32_t which, void *dst_host, size_t dst
     return CT_OK;
 }
 
+// The image changes under the convergence rule's feet (ct_upload, ct_set_subframes: a checkpoint is loaded): whatever
+// ct_set_stop_when_converged had frozen was the OLD image -- left in place, the flag would make every later accumulate
+// kernel return early and the new image's samples would be dropped without a word.  As in ct_reset.
+static int clear_freeze(CtHandle h)
+{
+    HIPCHK(h, hipMemsetAsync(h->d_freeze, 0, 8 * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memset(h->freeze_host, 0, 4 * sizeof(uint32_t));
+    return CT_OK;
+}
+
 extern "C" int ct_upload(CtHandle h, int32_t which, const void *src_host, size_t src_bytes)
 {
     NEED(h);
@@ -2730,8 +2798,7 @@ extern "C" int ct_upload(CtHandle h, int32_t which, const void *src_host, size_t
     }
     discard_ahead(h);   // (what was rendered ahead belongs to the image that is being replaced)
     HIPCHK(h, hipMemcpyAsync(p, src_host, b, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return CT_OK;
+    return clear_freeze(h);
 }
 
 extern "C" int ct_copy_to_device(CtHandle h, int32_t which, void *dst_dev, size_t dst_bytes)
@@ -2791,7 +2858,7 @@ extern "C" int ct_set_subframes(CtHandle h, uint32_t count)
     NEED(h);
     h->subframes = count;
     discard_ahead(h);
-    return CT_OK;
+    return clear_freeze(h);
 }
 
 extern "C" int ct_counters(CtHandle h, CtCounters *out)
@@ -2892,6 +2959,72 @@ extern "C" int ct_debug_stats_ex(CtHandle h, uint64_t *out, uint32_t count)
     return CT_OK;
 }
 
+// The estimator's working set: which 128-B lines of the density array it reads (march bricks for MARCH; apron or twin bricks
+// for DELTA) and of the shadow volume's apron bricks a launch fetches from.  Needs the diagnostics kernels (CT_STATS=1 or
+// CT_DEBUG_INVARIANTS=1 at ct_create).  enable != 0 allocates and clears the two bitmaps; 0 frees them.
+extern "C" int ct_debug_track_lines(CtHandle h, int32_t enable)
+{
+    NEED(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 2; k++) {
+        if (h->d_touched[k]) {
+            HIPCHK(h, hipFree(h->d_touched[k]));
+            h->d_touched[k] = nullptr;
+        }
+    }
+    if (!enable) {
+        return CT_OK;
+    }
+    if (!h->shape.stats) {
+        return fail(h, CT_E_STATE, "ct_debug_track_lines needs the diagnostics kernels (CT_STATS=1 at ct_create)");
+    }
+    if (h->dev.m_rows) {
+        return fail(h, CT_E_STATE, "ct_debug_track_lines: not implemented for sparse march bricks");
+    }
+    const size_t apron_lines = (size_t)h->dev.brick_gxy * (size_t)h->dev.brick_gz;
+    size_t density_lines = apron_lines;
+    if (h->scene.estimator == CT_EST_MARCH) {
+        density_lines = h->mbricks_dense_bytes / 128;
+    } else if (h->dev.delta_nee == 2u && h->dev.tbricks) {
+        density_lines = (size_t)h->dev.t_gx * h->dev.t_gy * h->dev.t_gz;
+    }
+    h->touched_lines[0] = density_lines;
+    h->touched_lines[1] = apron_lines;
+    for (int k = 0; k < 2; k++) {
+        const size_t words = (h->touched_lines[k] + 31) / 32;
+        HIPCHK(h, dmalloc(&h->d_touched[k], words));
+        HIPCHK(h, hipMemsetAsync(h->d_touched[k], 0, words * sizeof(uint32_t), h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CT_OK;
+}
+
+// out[0], out[1] = distinct lines touched in the density / shadow arrays since ct_debug_track_lines(h, 1) (or since the last
+// call with clear != 0), out[2], out[3] = the arrays' sizes in lines.  Waits for the batches in flight.
+extern "C" int ct_debug_touched_lines(CtHandle h, uint64_t out[4], int32_t clear)
+{
+    NEED(h);
+    if (!out || !h->d_touched[0]) {
+        return fail(h, CT_E_STATE, "ct_debug_touched_lines: call ct_debug_track_lines(h, 1) first");
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 2; k++) {
+        const size_t words = (h->touched_lines[k] + 31) / 32;
+        std::vector<uint32_t> bits(words);
+        HIPCHK(h, hipMemcpy(bits.data(), h->d_touched[k], words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t n = 0;
+        for (uint32_t w : bits) {
+            n += (uint64_t)__builtin_popcount(w);
+        }
+        out[k] = n;
+        out[2 + k] = h->touched_lines[k];
+        if (clear) {
+            HIPCHK(h, hipMemset(h->d_touched[k], 0, words * sizeof(uint32_t)));
+        }
+    }
+    return CT_OK;
+}
+
 extern "C" int ct_debug_memory(CtHandle h, uint64_t out[8])
 {
     NEED(h);
@@ -2952,6 +3085,43 @@ extern "C" int ct_debug_fetch_probe(int32_t device, uint32_t log2_lines, uint32_
     hipError_t e = hipSuccess;
     for (uint32_t r = 0; r < repeats && e == hipSuccess; r++) {
         e = launch_fetch_probe(buf, log2_lines, (r & 1u) ? 72u : 25u, sum, nullptr); // odd repeats touch both 64-B halves
+    }
+    if (e == hipSuccess) {
+        e = hipDeviceSynchronize();
+    }
+    unsigned long long v = 0;
+    hipMemcpy(&v, sum, 8, hipMemcpyDeviceToHost);
+    hipFree(buf);
+    hipFree(sum);
+    if (sum_out) {
+        *sum_out = v;
+    }
+    return e == hipSuccess ? CT_OK : fail(nullptr, CT_E_HIP, "fetch probe failed: %s", hipGetErrorString(e));
+}
+
+// The same access shape over a WORKING SET: 2^log2_threads lanes each read one pseudo-random line out of `ws_lines` lines, so
+// a set smaller than a cache level is re-read from that level (2^25 lanes over 2^20 lines = 128 MiB: every line 32 times per
+// launch, far apart in time) -- the line-fill ceiling of the level the set fits in (L2 4 MiB per XCD, Infinity Cache 256 MiB,
+// HBM beyond).  `repeats` launches; time two calls with different repeats and take the difference.
+extern "C" int ct_debug_fetch_probe_ws(int32_t device, uint32_t log2_threads, uint64_t ws_lines, uint32_t repeats, uint64_t *sum_out)
+{
+    if (log2_threads < 10 || log2_threads > 28 || ws_lines < 1024 || ws_lines > (1ull << 28) || hipSetDevice(device) != hipSuccess) {
+        return fail(nullptr, CT_E_INVAL, "ct_debug_fetch_probe_ws: bad device or size");
+    }
+    uint8_t *buf = nullptr;
+    unsigned long long *sum = nullptr;
+    const size_t bytes = (size_t)128 * ws_lines;
+    if (hipMalloc((void **)&buf, bytes) != hipSuccess || hipMalloc((void **)&sum, 8) != hipSuccess) {
+        if (buf) {
+            hipFree(buf);
+        }
+        return fail(nullptr, CT_E_NOMEM, "ct_debug_fetch_probe_ws: out of device memory");
+    }
+    hipMemset(buf, 0, bytes);
+    hipMemset(sum, 0, 8);
+    hipError_t e = hipSuccess;
+    for (uint32_t r = 0; r < repeats && e == hipSuccess; r++) {
+        e = launch_fetch_probe_ws(buf, log2_threads, (uint32_t)ws_lines, r, sum, nullptr);
     }
     if (e == hipSuccess) {
         e = hipDeviceSynchronize();

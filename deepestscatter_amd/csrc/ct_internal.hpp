@@ -92,6 +92,10 @@ struct BatchArgs {
     unsigned long long *counters; // kCounterCount
     unsigned long long *stats;    // kStatCount
     unsigned long long *timeline; // diagnostics (CT_TIMELINE=1), else NULL: per wave [start, end] on the 100 MHz wall clock
+    // diagnostics (ct_debug_track_lines; STATS kernels only), else NULL: one bit per 128-B line of the density array the
+    // estimator reads (march bricks / apron bricks / twin bricks) and of the shadow volume's apron bricks, set when a launch
+    // fetches from the line -- the kernel's working set, to be held against the 256 MiB of the Infinity Cache
+    uint32_t *touched_density, *touched_shadow;
 };
 
 struct LaunchShape {
@@ -170,7 +174,7 @@ hipError_t launch_accumulate_list(const float4 *frames, uint32_t frame_stride, c
                                   uint32_t shard_index, uint32_t shard_count, unsigned long long *bad_samples,
                                   const uint32_t *frozen, hipStream_t stream);
 hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure,
-                           float *column_sums, float *avg, uchar4 *screen, uint32_t *generation, hipStream_t stream);
+                           float *column_sums, float *avg, uchar4 *screen, uint32_t *generation, int device, hipStream_t stream);
 hipError_t launch_converged(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,
                             unsigned long long *unconverged, hipStream_t stream);
 hipError_t launch_converged_freeze(const float4 *mean, const float4 *m2, uint32_t subframe_id, uint64_t pixels,
@@ -180,6 +184,8 @@ hipError_t launch_cdf_selftest(const float *cdf, const uint16_t *guide, uint32_t
 hipError_t launch_math_selftest(int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *out, hipStream_t stream);
 hipError_t launch_fetch_probe(const uint8_t *buf, uint32_t log2_lines, uint32_t second_offset,
                               unsigned long long *sum, hipStream_t stream);
+hipError_t launch_fetch_probe_ws(const uint8_t *buf, uint32_t log2_threads, uint32_t ws_lines, uint32_t salt, unsigned long long *sum,
+                                 hipStream_t stream);
 hipError_t launch_point_rays(const DevScene &sc, const void *tasks, uint32_t n, uint32_t n_pad, float4 *primary,
                              uint32_t *pixels, hipStream_t stream);
 hipError_t launch_point_accumulate(const float4 *frames, uint32_t stride, void *tasks, uint32_t n, uint32_t launches,
@@ -199,11 +205,13 @@ hipError_t launch_mip_level(const uint8_t *prev, int px, int py, int pz, uint8_t
 hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const float *positions, const float *directions,
                               uint32_t count, float level0, float voxel_m, float cloud_size_m, uint8_t *out,
                               hipStream_t stream);
-LaunchShape persistent_shape(int device, bool delta);
+LaunchShape persistent_shape(int device, bool delta, int blocks_per_cu = 0);   // blocks_per_cu: 0 = as many as fit
+#ifdef CT_EXPERIMENTS
 // The estimators with a block-wide exchange of paths between waves (ct_exchange.hpp): one 1024-thread block per CU.
 LaunchShape exchange_shape(int device);
 hipError_t launch_render_delta_x(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
 LaunchShape wave_exchange_shape(int device);   // the exchange within a wave (render_delta_w_kernel): pool_slots = slots per wave
 hipError_t launch_render_delta_w(const DevScene &sc, const BatchArgs &ba, LaunchShape shape, hipStream_t stream);
+#endif
 
 } // namespace ct

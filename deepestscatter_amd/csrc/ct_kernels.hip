@@ -1322,6 +1322,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     nee_fetched = !nee_reused;
                     if (STATS) {
                         st_first += nee_reused ? 1u : 0u;
+                        if (ba.touched_shadow && !nee_reused) {
+                            const uint32_t line = (uint32_t)(apron_offset_in_grid(sc, pos) >> 7);
+                            atomicOr(&ba.touched_shadow[line >> 5], 1u << (line & 31u));
+                        }
                     }
                     c_il += 1;
                     work += 4u;
@@ -1425,6 +1429,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                         const uint32_t line = __umul24(lz >> 2, (uint32_t)sc.m_gxy) + __umul24(ly >> 2, (uint32_t)sc.m_gx) + (__umul24(lx, 43691u) >> 17);
                         st_same_line += (line == st_prev_line) ? 1u : 0u;
                         st_prev_line = line;
+                        if (ba.touched_density && !SPARSE) {   // ct_debug_track_lines: the distinct 128-B lines a launch reads
+                            atomicOr(&ba.touched_density[line >> 5], 1u << (line & 31u));
+                        }
                         const uint64_t act = __builtin_amdgcn_ballot_w64(true);
                         bool dup = false;
                         for (uint32_t i = 0; i < 64u; i++) {
@@ -2217,6 +2224,10 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                         if (STATS) {
                             st_fetch += 1;
                             st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
+                            if (ba.touched_density) {   // ct_debug_track_lines
+                                const uint32_t line = (uint32_t)((NEE == 2 ? twin_offset_in_grid(sc, p) : apron_offset_in_grid(sc, p)) >> 7);
+                                atomicOr(&ba.touched_density[line >> 5], 1u << (line & 31u));
+                            }
                         }
                         real = z * sigma_bar < filter_at(sc, cell, p) * sc.density_multiplier;
                     }
@@ -2224,6 +2235,10 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                         pos = p;
                         if (in_box(sc, pos)) {
                             state = ST_BOUNCE;
+                            if (STATS && ba.touched_shadow) {   // (twin bricks: the shadow half lies in the density's line)
+                                const uint32_t line = (uint32_t)((NEE == 2 ? twin_offset_in_grid(sc, p) : apron_offset_in_grid(sc, p)) >> 7);
+                                atomicOr(&(NEE == 2 ? ba.touched_density : ba.touched_shadow)[line >> 5], 1u << (line & 31u));
+                            }
                             if (NEE == 1) {
                                 nee_raw = load_raw_apron(sc.ibricks + off);
                             } else if (NEE == 2) {
@@ -2407,9 +2422,13 @@ hipError_t launch_render_delta(const DevScene &sc, const BatchArgs &ba, LaunchSh
     return hipGetLastError();
 }
 
+// The measured-and-rejected experiments (two DELTA kernels that regroup paths by phase: DESIGN.md 4.2 "Round 3") are not part
+// of the product's library: -DCT_EXPERIMENTS (python -m deepestscatter_amd.build --variant exp -> libcloudtrace_exp.so).
+#ifdef CT_EXPERIMENTS
 #include "ct_exchange.hpp"
+#endif
 
-LaunchShape persistent_shape(int device, bool delta)
+LaunchShape persistent_shape(int device, bool delta, int blocks_per_cu)
 {
     hipDeviceProp_t prop;
     LaunchShape s{ 1024, delta ? kDeltaThreads : 512, false };
@@ -2423,11 +2442,8 @@ LaunchShape persistent_shape(int device, bool delta)
             per_cu = delta ? 2 : 3;
         }
         s.blocks = prop.multiProcessorCount * std::min(per_cu, 8);
-        if (const char *e = getenv("CT_BLOCKS_PER_CU")) {   // tuning knob for experiments
-            const int v = atoi(e);
-            if (v >= 1 && v <= 8) {
-                s.blocks = prop.multiProcessorCount * v;
-            }
+        if (blocks_per_cu >= 1 && blocks_per_cu <= 8) {   // (CT_BLOCKS_PER_CU: tuning knob for experiments)
+            s.blocks = prop.multiProcessorCount * blocks_per_cu;
         }
     }
     return s;
@@ -2935,12 +2951,14 @@ __global__ __launch_bounds__(kReinhardThreads) void reinhard_fused_kernel(const 
 }
 
 // `avg` points at two words: the average luminance and the grid barrier's counter.  `generation` (host, one per `avg`)
-// counts the launches on that counter; 0 = the counter is to be zeroed first.
+// counts the launches that have ARRIVED at that counter; 0 = the counter is to be zeroed first.  `device` is the handle's
+// device (not the calling thread's current one): the barrier needs every block resident, one per CU at most, and every
+// launch on a counter must have the same block count.
 hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, float exposure, float *column_sums,
-                           float *avg, uchar4 *screen, uint32_t *generation, hipStream_t stream)
+                           float *avg, uchar4 *screen, uint32_t *generation, int device, hipStream_t stream)
 {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) {
         cus = 64;
     }
     const uint32_t pixels = width * height;
@@ -2957,10 +2975,13 @@ hipError_t launch_reinhard(const float4 *mean, uint32_t width, uint32_t height, 
         }
         gen = 0;
     }
-    gen += 1;
     hipLaunchKernelGGL(reinhard_fused_kernel, dim3(blocks), dim3(kReinhardThreads), width * sizeof(float), stream, mean, width, height,
-                       exposure, column_sums, avg, (uint32_t *)(avg + 1), gen * blocks, screen);
-    return hipGetLastError();
+                       exposure, column_sums, avg, (uint32_t *)(avg + 1), (gen + 1u) * blocks, screen);
+    const hipError_t e = hipGetLastError();
+    // A launch that did not happen never arrives at the counter: counting it would make every later tonemap wait in its grid
+    // barrier for arrivals that cannot come.  On failure the counter is re-zeroed before the next launch.
+    gen = (e == hipSuccess) ? gen + 1u : 0u;
+    return e;
 }
 
 // =============================================================================================
@@ -3150,6 +3171,34 @@ __global__ void fetch_probe_kernel(const uint8_t *__restrict__ buf, uint32_t lin
     if (v == magic) { // a run-time value the zeroed buffer never produces; keeps the loads alive
         atomicAdd(sum, 1ull);
     }
+}
+
+// Working-set variant: lane i reads line hash(i, salt) mod ws_lines (multiply-shift range reduction: uniform over any count).
+__global__ void fetch_probe_ws_kernel(const uint8_t *__restrict__ buf, uint32_t ws_lines, uint32_t salt, uint32_t magic,
+                                      unsigned long long *sum)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t hsh = (i ^ (salt * 0x9e3779b9u)) * 2654435761u;
+    hsh ^= hsh >> 15;
+    hsh *= 2246822519u;
+    hsh ^= hsh >> 13;
+    const uint32_t line = (uint32_t)(((uint64_t)hsh * ws_lines) >> 32);
+    const uint8_t *p = buf + ((size_t)line << 7) + 13;
+    uint2 a, c;
+    __builtin_memcpy(&a, p, 8);
+    __builtin_memcpy(&c, p + 25, 8);
+    const uint32_t v = a.x ^ a.y ^ c.x ^ c.y;
+    if (v == magic) {
+        atomicAdd(sum, 1ull);
+    }
+}
+
+hipError_t launch_fetch_probe_ws(const uint8_t *buf, uint32_t log2_threads, uint32_t ws_lines, uint32_t salt, unsigned long long *sum,
+                                 hipStream_t stream)
+{
+    const uint32_t n = 1u << log2_threads;
+    hipLaunchKernelGGL(fetch_probe_ws_kernel, dim3(n / 256), dim3(256), 0, stream, buf, ws_lines, salt, 0xdeadbeefu, sum);
+    return hipGetLastError();
 }
 
 hipError_t launch_fetch_probe(const uint8_t *buf, uint32_t log2_lines, uint32_t second_offset,

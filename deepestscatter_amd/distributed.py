@@ -33,8 +33,9 @@ def frame_gather(local, indices: list, packed, recv: list | None, dst: int = 0):
     indices) from `local` [2, H, W, 4] into `packed` [2, n_max, 4], the packs are gathered on rank `dst`, which writes each
     into its place.  `recv`: world tensors like `packed` on rank dst, None elsewhere.  Exact: no arithmetic at all."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_available() and dist.is_initialized()):
         return local
+    # (a process group of ONE rank still goes through the backend: the single-GPU rehearsal of this path on RCCL)
     rank = dist.get_rank()
     flat = local.view(2, -1, 4)
     n = indices[rank].numel()
@@ -57,7 +58,7 @@ def frame_reduce(local, dst: int = 0):
     """SUM-reduce a per-rank radiance buffer (torch tensor, any device) to rank `dst`.  Tiles are
     disjoint and foreign pixels are exactly 0, so the sum is the merged frame."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         if local.is_cuda and dist.get_backend() != "nccl":
             # rehearsal on a backend without device collectives (gloo): stage through the host
             host = local.cpu()
@@ -86,8 +87,11 @@ class ShardedTracer:
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
-        self.merge = merge if world > 1 else "reduce"   # "gather": every rank sends only its own tiles (1/world of the bytes)
+        # "gather": every rank sends only its own tiles (1/world of the bytes); a single rank merges only when it is asked to
+        # stage (stage_always: the one-GPU rehearsal, which then runs the chosen collective on a group of one)
+        self.merge = merge if (world > 1 or stage_always) else "reduce"
         self._merge_events, self._merge_host_ms, self._merges = [], 0.0, 0
+        self._merge_dev_ms, self._merge_dev_n = 0.0, 0
         params.shard_index, params.shard_count, params.device = rank, world, local_rank
         self.tracer = CloudTracer(density, params)
         self.stage = world > 1 or stage_always       # stage_always: single-rank rehearsal of the staged path
@@ -144,6 +148,12 @@ class ShardedTracer:
         self._reduce()
         e1.record(self.stream)
         self._merge_events.append((e0, e1))
+        # (a long progressive run merges once per step: finished pairs are folded into a running sum, so neither the list nor
+        # merge_ms() grows with the number of steps)
+        while len(self._merge_events) > 8 and self._merge_events[0][1].query():
+            a, b = self._merge_events.pop(0)
+            self._merge_dev_ms += a.elapsed_time(b)
+            self._merge_dev_n += 1
         self._merge_host_ms += (time.perf_counter() - t0) * 1e3
         self._merges += 1
 
@@ -156,7 +166,11 @@ class ShardedTracer:
         if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
             return self._merge_host_ms / self._merges
         self.stream.synchronize()
-        return sum(a.elapsed_time(b) for a, b in self._merge_events) / len(self._merge_events)
+        for a, b in self._merge_events:
+            self._merge_dev_ms += a.elapsed_time(b)
+            self._merge_dev_n += 1
+        self._merge_events.clear()
+        return self._merge_dev_ms / max(self._merge_dev_n, 1)
 
     def step(self, first_subframe: int, count: int):
         """Render + accumulate `count` subframes of this shard, then reduce [mean | M2] to rank 0.

@@ -400,6 +400,21 @@ CT_API int ct_debug_memory(CtHandle h, uint64_t out[8]);
  * load to byte 85 so that both 64-byte halves of the line are touched.  Returns a checksum. */
 CT_API int ct_debug_fetch_probe(int32_t device, uint32_t log2_lines, uint32_t repeats, uint64_t *sum_out);
 
+/* The same access shape over a WORKING SET of `ws_lines` 128-byte lines: each of 2^log2_threads lanes reads one
+ * pseudo-random line of the set, so a set smaller than a cache level is re-read from that level -- the random-line
+ * fill ceiling of L2 (4 MiB per XCD), of the Infinity Cache (256 MiB) and of HBM, by size.  `repeats` launches;
+ * time two calls with different repeat counts and divide the difference. */
+CT_API int ct_debug_fetch_probe_ws(int32_t device, uint32_t log2_threads, uint64_t ws_lines, uint32_t repeats, uint64_t *sum_out);
+
+/* The estimator's working set (diagnostics kernels: CT_STATS=1 or CT_DEBUG_INVARIANTS=1 at ct_create).
+ * ct_debug_track_lines(h, 1) allocates and clears one bit per 128-byte line of the density array the estimator reads
+ * (MARCH: march bricks; DELTA: apron or twin bricks) and of the shadow volume's apron bricks; every fetch of a later
+ * launch sets its line's bit; (h, 0) frees them.  ct_debug_touched_lines waits for the batches in flight and returns
+ * out[0], out[1] = distinct lines touched (density, shadow), out[2], out[3] = lines in the two arrays; clear != 0
+ * resets the bits. */
+CT_API int ct_debug_track_lines(CtHandle h, int32_t enable);
+CT_API int ct_debug_touched_lines(CtHandle h, uint64_t out[4], int32_t clear);
+
 /* Self-test hook: the kernels' short correctly-rounded reciprocal (which = 0) and square root (which = 1) against the IEEE
  * operations for EVERY float of their range, 2^-60 <= |x| < 2^61 (reciprocal: both signs), on the device:
  * out[0] = floats tested, out[1] = mismatches (must be 0), out[2] = smallest mismatching bit pattern or 0xffffffff. */

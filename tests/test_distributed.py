@@ -90,3 +90,86 @@ def test_whole_bench_under_torchrun_with_two_ranks_on_one_gpu(merge):
     assert out["rccl_ranks"] == m["rccl_ranks"] == m["world_size"] == 2 and m["backend"] == "gloo" and m["merge"] == merge
     assert len(m["ms_per_step_per_rank"]) == 2 and all(v > 0 for v in m["ms_per_step_per_rank"])
     assert len(m["merge_ms_per_step_per_rank"]) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("merge", ["reduce", "gather"])
+def test_sharded_tracer_merges_through_an_nccl_group_of_one_rank(merge):
+    """The N > 1 merge on the real backend: torch.distributed "nccl" (= RCCL) initialised with ONE rank on the box's GPU,
+    ShardedTracer staging and merging as it does for N ranks (reduce, and the gather of every rank's own tiles), enqueued and
+    waited-for steps, tonemap of the merged frame.  gloo covers the multi-rank arithmetic (above); this covers RCCL, the
+    device tensors and the stream ordering between the library's copies and torch's collective."""
+    import subprocess
+    port = 29900 + (os.getpid() % 90)
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "_nccl_one_rank.py"), merge, str(port)], capture_output=True, text=True,
+                       timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0 and f"nccl one-rank merge ok: {merge}" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_eight_shards_at_full_size_merge_into_the_whole_frame():
+    """BASELINE.json configs[3] at its own size: 512^3 / 1024^2 cut into EIGHT pixel-tile shards (2 subframes).  The eight
+    handles' means and M2s sum to the single handle's frame bit for bit, the lookups and paths add up, and the same eight
+    shards driven below the C ABI (ct_group_* with the device repeated eight times: merged by copies and an add kernel, since
+    RCCL refuses two ranks per device) give that frame, its tonemap and its convergence count too."""
+    import deepestscatter_amd as ds
+    tex = ds.make_procedural_cloud(512)
+    w = h = 1024
+    whole = ds.CloudTracer(tex, width=w, height=h)
+    whole.render_accumulate(1, 2)
+    want = (whole.mean(), whole.m2(), whole.counters(), whole.tonemap(0.4), whole.is_converged())
+    whole.close()
+    mean, m2 = np.zeros_like(want[0]), np.zeros_like(want[1])
+    total = {}
+    covered = np.zeros((h, w), np.int32)
+    for r in range(8):
+        sh = ds.CloudTracer(tex, width=w, height=h, shard_index=r, shard_count=8)
+        sh.render_accumulate(1, 2)
+        m = sh.mean()
+        mask = ds.shard_mask(w, h, r, 8)
+        assert not m[~mask].any()                       # foreign pixels are exactly zero: SUM is a merge
+        covered += mask
+        mean += m
+        m2 += sh.m2()
+        for k, v in sh.counters().items():
+            total[k] = total.get(k, 0) + v
+        sh.close()
+    assert covered.min() == 1 and covered.max() == 1
+    assert np.array_equal(mean, want[0]) and np.array_equal(m2, want[1]) and total == want[2]
+    g = ds.TracerGroup(tex, [0] * 8, width=w, height=h)
+    g.render_accumulate(1, 2)
+    assert np.array_equal(g.mean(), want[0]) and np.array_equal(g.m2(), want[1]) and g.counters() == want[2]
+    screen, avg = g.tonemap(0.4)
+    assert np.array_equal(screen, want[3][0]) and avg == want[3][1]
+    assert g.is_converged() == want[4]
+    g.close()
+
+
+@pytest.mark.gpu
+def test_bench_group_mode_and_torchrun_mode_produce_the_same_frame():
+    """Two independent N-GPU implementations behind one bench line: `bench.py --gpus 2 --group` (ONE process, ct_group_* below
+    the C ABI) and the torchrun path (one rank per shard over torch.distributed).  Both print the SHA-256 of the merged
+    [mean | M2] frame; on this box's one GPU (shards sharing the device, gloo / the add kernel standing in for RCCL) the two
+    hashes must equal each other and the N = 1 frame's -- the comparison the driver's 8-GPU node can repeat on RCCL."""
+    import json
+    import subprocess
+    common = ["--steps", "2", "--warmup", "1", "--volume", "64", "--width", "128", "--height", "96", "--spp-per-step", "24", "--no-cpu-baseline",
+              "--no-pmc-traffic", "--no-delta-leg", "--no-progressive-leg"]
+    port = 29800 + (os.getpid() % 90)
+    cmds = {
+        "single": [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", *common],
+        "group": [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--group", "--single-device", *common],
+        "torchrun": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", *common],
+    }
+    got = {}
+    for name, cmd in cmds.items():
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+        assert r.returncode == 0, name + ": " + r.stdout[-1500:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+        assert len(lines) == 1, name
+        got[name] = json.loads(lines[0])
+        assert got[name]["subframes_in_the_frame"] == 72 and got[name]["value"] > 0
+    assert got["group"]["n_gpus"] == 2 and got["group"]["multi_gpu"]["implementation"].startswith("ct_group")
+    assert got["single"]["frame_sha256"] == got["group"]["frame_sha256"] == got["torchrun"]["frame_sha256"]
+

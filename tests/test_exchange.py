@@ -1,55 +1,51 @@
-"""The experimental DELTA kernels that regroup paths by phase (deepestscatter_amd/csrc/ct_exchange.hpp; run with -m gpu).
+"""The measured-and-rejected DELTA kernels that regroup paths by phase (csrc/ct_exchange.hpp) live in the EXPERIMENTS build of
+the library (libcloudtrace_exp.so: python -m deepestscatter_amd.build --variant exp), not in the product's: their parity cases
+(tests/exchange_cases.py) therefore run in a child process that loads that build (CT_LIBRARY), while this process keeps the
+product's library.  The product's library must not contain them, and must say so when asked for them."""
+import os
+import subprocess
+import sys
+from pathlib import Path
 
-CT_EXCHANGE=1: block-wide exchange of paths between the 16 waves of a workgroup (slots + three rings in LDS);
-CT_EXCHANGE=2: the same regrouping within a wave (private lists, no atomics).  Neither is the default -- both measured
-slower than render_delta_kernel (profiles/r03c, r03d) -- but both must produce its results bit for bit:
-a path's arithmetic does not depend on the lane, the wave or the order it runs in.
-"""
 import numpy as np
 import pytest
 
-import _oracle as O
-import deepestscatter_amd as ds
-
-pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
-@pytest.mark.parametrize("n,size,mode", [(40, 56, 0), (48, 64, 1), (40, 64, 2)])
-def test_exchange_kernels_equal_the_oracle_bit_for_bit(variant, n, size, mode, monkeypatch):
-    monkeypatch.setenv("CT_EXCHANGE", variant)
-    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")      # NaN-filled scratch + samples dealt == results written
-    tex = ds.make_procedural_cloud(n)
-    tr = ds.CloudTracer(tex, width=size, height=size, mode=mode, estimator=1)
-    tr.render_accumulate(1, 8)          # the cost-measuring launch of a pose keeps the per-lane kernel
-    tr.render_accumulate(9, 8)          # exchange kernel
-    tr.render_accumulate(17, 48)        # exchange kernel, long enough for the lists / rings to wrap
-    spp = 64
-    mean, m2, c = tr.mean(), tr.m2(), tr.counters()
-    st, iv = tr.debug_stats(), tr.debug_invariants()
-    orc = O.Oracle(tex, size, size, mode=mode, fast=True, estimator=1, inscatter=tr.inscatter())
-    rm, rm2 = orc.render(spp)
-    tr.close()
-    assert st["watchdog"] == 0                          # no wave gave up on a bounded wait
-    assert iv["armed"] == 1 and iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
-    assert c == orc.counters.as_dict()
-    assert np.array_equal(mean, rm) and np.array_equal(m2, rm2)
+def _kernel_names(path):
+    out = subprocess.run(["strings", "-n", "12", str(path)], capture_output=True, text=True).stdout
+    return {l.strip() for l in out.splitlines() if "_kernel" in l and l.startswith("_ZN2ct")}
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
-def test_exchange_kernels_on_the_benchmark_scene_equal_the_per_lane_kernel(variant, monkeypatch):
-    """512^3 / 1024^2 (16-texel majorant cells, every block busy): 24 subframes, whole frame, against render_delta_kernel."""
-    tex = ds.make_procedural_cloud(512)
-    ref = ds.CloudTracer(tex, width=1024, height=1024, estimator=1)
-    ref.render_accumulate(1, 24)
-    want = (ref.mean(), ref.m2(), ref.counters())
-    ref.close()
-    monkeypatch.setenv("CT_EXCHANGE", variant)
-    tr = ds.CloudTracer(tex, width=1024, height=1024, estimator=1)
-    tr.render_accumulate(1, 8)
-    tr.render_accumulate(9, 16)
-    got = (tr.mean(), tr.m2(), tr.counters())
-    st = tr.debug_stats()
-    tr.close()
-    assert st["watchdog"] == 0 and got[2] == want[2]
-    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+def test_the_products_library_holds_the_products_kernels_only():
+    from deepestscatter_amd import _lib, build
+    names = _kernel_names(build.LIB)
+    assert any("render_persistent_kernel" in n for n in names) and any("render_delta_kernel" in n for n in names)
+    assert not any("render_delta_x_kernel" in n or "render_delta_w_kernel" in n for n in names)
+    exp = build.PKG / "libcloudtrace_exp.so"
+    if exp.exists():
+        assert any("render_delta_x_kernel" in n for n in _kernel_names(exp))
+    assert _lib.LIB_PATH.name == "libcloudtrace.so" or os.environ.get("CT_LIBRARY")
+
+
+@pytest.mark.gpu
+def test_exchange_kernels_in_the_experiments_build():
+    from deepestscatter_amd import build
+    build.build_variant("exp")
+    env = dict(os.environ, CT_LIBRARY="libcloudtrace_exp.so")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", str(ROOT / "tests" / "exchange_cases.py")],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_the_products_library_refuses_the_experiments_knob(monkeypatch):
+    import deepestscatter_amd as ds
+    from deepestscatter_amd import _lib
+    monkeypatch.setenv("CT_EXCHANGE", "1")
+    tex = np.zeros((16, 16, 16), np.uint8)
+    tex[4:12, 4:12, 4:12] = 200
+    with pytest.raises(_lib.CloudTraceError) as e:
+        ds.CloudTracer(tex, width=16, height=16, estimator=1)
+    assert e.value.code == _lib.CT_E_INVAL and "experiments build" in e.value.message

@@ -978,6 +978,9 @@ def test_scheduler_knobs_never_change_a_result(monkeypatch, estimator):
         {"CT_NO_ADVANCE": "1"}, {"CT_CONTINUATION": "0"}, {"CT_HINT_PERIOD": "1"}, {"CT_HINT_PERIOD": "0"},
         {"CT_TAIL_BURST": "1"}, {"CT_BURST_MARCH_MIN": "20"}, {"CT_NEE_CACHE": "0"},
         {"CT_SPARSE": "1"}, {"CT_SPARSE": "1", "CT_XCD_QUEUES": "1", "CT_NO_ADVANCE": "1"},
+        # the DELTA kernel's fetch layouts (round 4): separate bricks / shadow footprint requested at the collision / twin bricks
+        {"CT_DELTA_NEE": "0"}, {"CT_DELTA_NEE": "1"}, {"CT_DELTA_NEE": "2"}, {"CT_DELTA_NEE": "2", "CT_CONTINUATION": "0"},
+        {"CT_DELTA_NEE": "2", "CT_XCD_QUEUES": "1", "CT_NO_ADVANCE": "1"},
     ]
     for env in settings:
         for k, v in env.items():
@@ -987,6 +990,37 @@ def test_scheduler_knobs_never_change_a_result(monkeypatch, estimator):
             monkeypatch.delenv(k)
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
         assert got[2] == base[2], env
+
+
+@pytest.mark.parametrize("nee", ["0", "1", "2"])
+def test_delta_fetch_layouts_against_the_oracle(nee, monkeypatch):
+    """render_delta_kernel<.., NEE>: where a collision's density and shadow-volume footprints come from -- their own apron
+    bricks with the shadow fetch in the scatter phase (0), the same arrays with the shadow footprint requested in the tracking
+    visit (1), twin bricks of 3^3 base texels that hold both in one 128-byte line (2).  Same values whatever the layout: mean,
+    M2 and counters equal the oracle twin's on non-cubic volumes, a volume without a zero border (flights run into the apron,
+    where the twin grid's clamp applies), all three radiance programs, and with paths suspended between their collision and
+    their bounce (enqueued batches: the resumed path requests its shadow footprint again)."""
+    monkeypatch.setenv("CT_DELTA_NEE", nee)
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    rng = np.random.default_rng(7)
+    cases = [
+        (sphere_volume(dims=(23, 31, 17), seed=5), 40, 28, dict(mode=0, cloud_size_m=9000.0)),
+        (rng.integers(0, 256, (14, 19, 26)).astype(np.uint8), 33, 21, dict(mode=0, cloud_size_m=300.0, max_depth=60)),   # no border
+        (sphere_volume(dims=(40, 40, 40), radius=0.45, seed=9), 36, 36, dict(mode=1, cloud_size_m=4000.0, max_depth=300)),
+        (sphere_volume(dims=(29, 29, 29), seed=11), 32, 24, dict(mode=2)),
+    ]
+    for tex, w, h, kw in cases:
+        tr, orc = make_pair(tex, w, h, estimator=1, **kw)
+        tr.render_accumulate_async(1, 3)
+        tr.render_accumulate_async(4, 2)
+        tr.render_accumulate(6, 4)
+        tr.render_accumulate_async(10, 5)
+        mean, m2 = orc.render(14)
+        assert np.array_equal(tr.mean(), mean) and np.array_equal(tr.m2(), m2), (nee, tex.shape, kw)
+        assert tr.counters() == orc.counters.as_dict(), (nee, tex.shape, kw)
+        iv = tr.debug_invariants()
+        assert iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+        tr.close()
 
 
 def test_multi_gpu_step_on_the_rccl_backend_single_rank():
@@ -1475,6 +1509,53 @@ def test_checkpoint_and_resume_continue_exactly(estimator, tmp_path):
     with pytest.raises(_lib.CloudTraceError):
         b.upload(_lib.CT_BUF_SCREEN, np.zeros((h, w, 4), np.float32))
     b.close()
+
+
+def test_checkpoint_of_a_frozen_image_and_resume_into_a_frozen_handle(tmp_path):
+    """With ct_set_stop_when_converged the running mean freezes at the reference's stopping count N while the host keeps
+    submitting: a checkpoint taken then must pair the buffers with N, not with the host's count, and loading a checkpoint into
+    a handle whose image has frozen must release it -- or every later sample would be dropped silently.  Compared with a
+    handle that never had a stopping rule and renders straight through."""
+    tex = ds.make_procedural_cloud(64)
+    size, mode = 1024, 2                      # (the "crossing" case of the test below: fails at 10 subframes, passes at 20)
+    a = ds.CloudTracer(tex, width=size, height=size, mode=mode)
+    a.set_stop_when_converged(10, 10)
+    for k in range(5):
+        a.render_accumulate_async(10 * k + 1, 10)
+    a.synchronize()
+    frozen_at = a.converged_at()[0]
+    assert frozen_at == 20 and a.subframes == 50
+    a.save_state(tmp_path / "frozen")          # (no suffix: np.savez adds one, load_state must find the same file)
+    assert (tmp_path / "frozen.npz").exists()
+    straight = ds.CloudTracer(tex, width=size, height=size, mode=mode)
+    straight.render_accumulate(1, 20)
+    assert np.array_equal(a.mean(), straight.mean()) and np.array_equal(a.m2(), straight.m2())
+    straight.render_accumulate(21, 12)
+    want = (straight.mean(), straight.m2())
+    straight.close()
+    # a fresh handle continues from the frozen count ...
+    b = ds.CloudTracer(tex, width=size, height=size, mode=mode)
+    assert b.load_state(tmp_path / "frozen") == 20
+    b.render_accumulate(21, 12)
+    assert np.array_equal(b.mean(), want[0]) and np.array_equal(b.m2(), want[1])
+    b.close()
+    # ... and so does the frozen handle itself once the checkpoint is loaded into it (the stopping rule switched off first:
+    # left on, the image would pass the test again and stop again, which is the rule working, not samples getting lost)
+    a.set_stop_when_converged(0, 10)
+    assert a.load_state(tmp_path / "frozen.npz") == 20 and a.converged_at()[0] == 0
+    a.render_accumulate(21, 12)
+    assert np.array_equal(a.mean(), want[0]) and np.array_equal(a.m2(), want[1])
+    # with the rule left on and a checkpoint loaded: frozen flag cleared by the load, samples accumulate until the next test
+    a.set_stop_when_converged(10, 10)
+    a.load_state(tmp_path / "frozen")
+    a.render_accumulate(21, 5)                 # (no test falls inside: 25 is not a multiple of 10)
+    assert a.converged_at()[0] == 0 and not np.array_equal(a.mean(), b_mean_at_20(tmp_path))
+    a.close()
+
+
+def b_mean_at_20(tmp_path):
+    with np.load(tmp_path / "frozen.npz") as z:
+        return z["mean"]
 
 
 @pytest.mark.parametrize("estimator", [0, 1])

@@ -13,6 +13,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 
+os.environ.setdefault("CT_LIBRARY", "libcloudtrace_exp.so")   # the experiments build holds these kernels (build --variant exp)
 XMODE = os.environ.get("CT_EXCHANGE", "1")   # 1 = block-wide exchange, 2 = exchange within a wave
 
 

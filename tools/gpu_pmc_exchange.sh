@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC comparison of the per-lane DELTA kernel and the exchange kernel (same process, same job).  Usage (GPU box):
 #   tools/gpu_pmc_exchange.sh OUT_DIR [ENV...]
+export CT_LIBRARY=libcloudtrace_exp.so   # the exchange kernels live in the experiments build (python -m deepestscatter_amd.build --variant exp)
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp

@@ -17,7 +17,7 @@ CT_OK, CT_E_INVAL, CT_E_HIP, CT_E_NOMEM, CT_E_STATE, CT_E_NODEVICE, CT_E_RCCL = 
 CT_MODE_SUN_AND_SKY_ALL_SCATTER, CT_MODE_SUN_MULTIPLE_SCATTER, CT_MODE_SUN_SINGLE_SCATTER = 0, 1, 2
 CT_EST_MARCH, CT_EST_DELTA = 0, 1
 CT_BUF_MEAN, CT_BUF_M2, CT_BUF_FRAME, CT_BUF_SCREEN, CT_BUF_INSCATTER, CT_BUF_DENSITY = range(6)
-CT_FLAG_NONE, CT_FLAG_SIMPLE_KERNEL, CT_FLAG_LIGHT_NORMALIZED, CT_FLAG_SPARSE_BRICKS = 0, 1, 2, 4
+CT_FLAG_NONE, CT_FLAG_SIMPLE_KERNEL, CT_FLAG_LIGHT_NORMALIZED, CT_FLAG_SPARSE_BRICKS, CT_FLAG_VMM_BRICKS = 0, 1, 2, 4, 8
 
 # every symbol include/cloudtrace.h declares (tests check the library exports all of them)
 EXPORTS = [

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/cloudtrace.h"
@@ -69,6 +70,13 @@ struct CtHandle_ {
     uint2 *d_mrows = nullptr;          // sparse march bricks: extent of every brick row (DevScene::m_rows)
     uint8_t *d_mcoarse = nullptr;      // ... and the clearance of the coarse cells outside the extents
     size_t mbricks_dense_bytes = 0, mbricks_bytes = 0;
+    // CT_FLAG_VMM_BRICKS: d_mbricks is a reserved virtual range (not a hipMalloc), backed chunk by chunk
+    struct VmmBricks {
+        void *va = nullptr;
+        size_t size = 0, chunk = 0;
+        std::vector<hipMemGenericAllocationHandle_t> handles;   // one per chunk with memory of its own + the shared ones
+        size_t real_chunks = 0, shared_chunks = 0, mapped_chunks = 0;
+    } vmm;
     uint8_t *d_pyramid = nullptr;     // density mip pyramid, built on first use (ct_collect_descriptors)
     MipPyramid pyramid{};
     float *d_mie = nullptr, *d_chopped = nullptr, *d_cdf = nullptr;
@@ -398,6 +406,18 @@ static void release(CtHandle h)
     if (h->stream) {
         hipStreamSynchronize(h->stream);
     }
+#ifdef CT_EXPERIMENTS
+    if (h->vmm.va) {
+        // the march bricks live in a reserved virtual range: unmap, release the physical chunks, free the range
+        hipMemUnmap(h->vmm.va, h->vmm.size);
+        for (auto &hd : h->vmm.handles) {
+            hipMemRelease(hd);
+        }
+        hipMemAddressFree(h->vmm.va, h->vmm.size);
+        h->vmm.va = nullptr;
+        h->d_mbricks = nullptr;
+    }
+#endif
     void *ptrs[] = { h->d_density, h->d_inscatter, h->d_dbricks, h->d_ibricks, h->d_mbricks, h->d_tbricks, h->d_touched[0], h->d_touched[1], h->d_mrows, h->d_mcoarse, h->d_pyramid, h->d_mie, h->d_chopped, h->d_cdf,
                      h->d_guide, h->d_dist, h->d_dist_tmp, h->d_majorant, h->d_maj_cells, h->d_maj_codes, h->d_frame, h->d_mean, h->d_m2, h->d_screen, h->d_frames_all, h->cont[0], h->cont[1], h->left[0], h->left[1], h->d_cont_count, h->d_cont_total, h->d_primary, h->d_advance, h->d_pixels, h->d_cost, h->d_group_rank, h->d_group_order, h->d_job_group, h->d_job_sub, h->d_queue,
                      h->d_counters, h->d_colsum, h->d_avg, h->d_freeze, h->d_hit, h->d_cost_plane, h->d_timeline, h->pt.tasks, h->pt.primary, h->pt.frames, h->pt.pixels, h->pt.jg, h->pt.js };
@@ -442,6 +462,131 @@ static void release(CtHandle h)
     }
     delete h;
 }
+
+#ifdef CT_EXPERIMENTS
+// EXPERIMENTS BUILD ONLY (measured and rejected in round 4: a gather over memory mapped in 2-MiB pieces runs at 0.55 of the speed of
+// the same gather over one hipMalloc, whatever the layout -- DESIGN.md 4.3 item 7b, profiles/r04f, r04g).
+// CT_FLAG_VMM_BRICKS / CT_SPARSE=2 (BASELINE.json configs[4], "sparse brick-compressed density"): the dense march-brick array
+// h->d_mbricks is replaced by a reserved VIRTUAL range of the same size and layout in which chunks of the virtual-memory
+// granularity (2 MiB) SHARE memory wherever they may.  A chunk with a non-zero texel byte gets a copy of its own.  A chunk
+// without one is described by its meta bytes alone, and a clearance may be rounded down without changing a result (the exact
+// free-space skip gets shorter, nothing else): the clearances are quantised to {0, 4, 8, 16, 32, 64, 127} texels, and all
+// chunks whose quantised bytes are equal are mapped onto ONE piece of memory.  For that to happen chunk boundaries must fall
+// on brick-row boundaries, so this layout pads a brick row to a power of two bricks (create_impl).  The estimator's kernel is
+// the dense one, unchanged -- same address arithmetic, one more level of sharing in the page tables -- and its results are
+// identical (tests/test_gpu_parity.py: test_vmm_backed_march_bricks..., the knob test with CT_SPARSE=2; tests/test_configs.py).
+static int vmm_back_mbricks(CtHandle h)
+{
+    const size_t dense_bytes = h->mbricks_dense_bytes;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = h->device;
+    size_t gran = 0;
+    HIPCHK(h, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    const size_t chunk = std::max<size_t>(gran, (size_t)2 << 20);
+    if (chunk % 128 != 0 || (chunk & (chunk - 1)) != 0) {
+        return fail(h, CT_E_HIP, "virtual-memory granularity %zu is not a power of two", chunk);
+    }
+    const size_t n_chunks = (dense_bytes + chunk - 1) / chunk;
+    const size_t va_size = n_chunks * chunk;
+    uint4 *d_class = nullptr;
+    HIPCHK(h, dmalloc(&d_class, n_chunks));
+    std::vector<uint4> cls(n_chunks);
+    uint8_t *dense = h->d_mbricks;
+    void *va = nullptr;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    auto undo = [&]() {
+        if (va) {
+            hipMemUnmap(va, va_size);
+            for (auto &hd : handles) {
+                hipMemRelease(hd);
+            }
+            hipMemAddressFree(va, va_size);
+        }
+        hipFree(d_class);
+    };
+#define VMMCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        const hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                            \
+            undo();                                                                                        \
+            return fail(h, CT_E_HIP, "virtual-memory bricks: %s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                                  \
+    } while (0)
+    VMMCHK(launch_mbrick_chunk_class(dense, (int64_t)dense_bytes, (int64_t)chunk, d_class, h->stream));
+    VMMCHK(hipMemcpyAsync(cls.data(), d_class, n_chunks * sizeof(uint4), hipMemcpyDeviceToHost, h->stream));
+    VMMCHK(hipStreamSynchronize(h->stream));
+    VMMCHK(hipMemAddressReserve(&va, va_size, chunk, nullptr, 0));
+    // owner[c] = the chunk whose memory chunk c uses (itself: memory of its own)
+    std::vector<size_t> owner(n_chunks);
+    std::vector<hipMemGenericAllocationHandle_t> of_chunk(n_chunks);
+    std::map<uint64_t, size_t> first_with;
+    size_t own = 0, with_data = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        const bool whole = (c + 1) * chunk <= dense_bytes;   // (the last, partial chunk always gets memory of its own)
+        owner[c] = c;
+        if (whole && cls[c].x == 0u) {
+            const uint64_t key = (uint64_t)cls[c].z | (uint64_t)cls[c].w << 32;
+            const auto it = first_with.find(key);
+            if (it != first_with.end()) {
+                owner[c] = it->second;
+            } else {
+                first_with[key] = c;
+            }
+        } else {
+            with_data += 1;
+        }
+        void *at = (uint8_t *)va + c * chunk;
+        if (owner[c] == c) {
+            hipMemGenericAllocationHandle_t hd;
+            VMMCHK(hipMemCreate(&hd, chunk, &prop, 0));
+            handles.push_back(hd);
+            of_chunk[c] = hd;
+            own += 1;
+        } else {
+            of_chunk[c] = of_chunk[owner[c]];
+        }
+        VMMCHK(hipMemMap(at, chunk, 0, of_chunk[c], 0));
+    }
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    VMMCHK(hipMemSetAccess(va, va_size, &acc, 1));
+    for (size_t c = 0; c < n_chunks; c++) {
+        if (owner[c] != c) {
+            continue;
+        }
+        uint8_t *at = (uint8_t *)va + c * chunk;
+        const size_t n = std::min(chunk, dense_bytes - c * chunk);
+        VMMCHK(hipMemcpyAsync(at, dense + c * chunk, n, hipMemcpyDeviceToDevice, h->stream));
+        if (n < chunk) {
+            VMMCHK(hipMemsetAsync(at + n, 0, chunk - n, h->stream));
+        } else if (cls[c].x == 0u) {
+            VMMCHK(launch_mbrick_chunk_quantize(at, (int64_t)chunk, h->stream));   // others are mapped onto these bytes
+        }
+    }
+    VMMCHK(hipStreamSynchronize(h->stream));
+#undef VMMCHK
+    hipFree(d_class);
+    HIPCHK(h, hipFree(dense));
+    h->d_mbricks = (uint8_t *)va;
+    h->vmm.va = va;
+    h->vmm.size = va_size;
+    h->vmm.chunk = chunk;
+    h->vmm.handles = std::move(handles);
+    h->vmm.real_chunks = with_data;
+    h->vmm.shared_chunks = own - with_data;
+    h->vmm.mapped_chunks = n_chunks - own;
+    h->mbricks_bytes = own * chunk;
+    if (h->tune.STATS) {
+        fprintf(stderr, "[cloudtrace] march bricks, dense addressing with sparse backing: %zu chunks of %zu KiB, %zu with texels, %zu distinct "
+                        "empty ones, %zu mapped onto those: %.3f GB behind %.3f GB of addresses\n", n_chunks, chunk >> 10, with_data, own - with_data,
+                n_chunks - own, (double)(own * chunk) / 1e9, (double)va_size / 1e9);
+    }
+    return CT_OK;
+}
+#endif
 
 static int create_impl(const CtScene *s, CtHandle h)
 {
@@ -765,7 +910,30 @@ static int create_impl(const CtScene *s, CtHandle h)
         // volumes of the distance transform are borrowed from the shadow-volume brick array's
         // neighbourhood: plain temporaries, freed when the build has run.
         const int mbias = ((apron + 2) / 3) * 3;
-        const int64_t mgx = ((int64_t)nx + 2 * mbias + 2) / 3 + 1;
+        int64_t mgx = ((int64_t)nx + 2 * mbias + 2) / 3 + 1;
+        bool vmm = (s->flags & CT_FLAG_VMM_BRICKS) != 0;
+        bool pad_only = false;   // CT_SPARSE=3 (A/B): the padded rows of the virtual-memory layout in ordinary memory
+        if (const char *env = h->tune.SPARSE.get()) {
+            vmm = atoi(env) == 2 || atoi(env) == 4;
+            pad_only = atoi(env) == 3;
+        }
+        vmm = vmm && s->estimator == CT_EST_MARCH;
+#ifndef CT_EXPERIMENTS
+        if (vmm || pad_only) {
+            return fail(h, CT_E_INVAL, "march bricks behind virtual memory (CT_FLAG_VMM_BRICKS, CT_SPARSE=2..4) were measured and rejected "
+                                       "(DESIGN.md 4.3 item 7b): they exist in the experiments build only (build --variant exp; CT_LIBRARY=libcloudtrace_exp.so)");
+        }
+#endif
+        const bool no_pad = h->tune.SPARSE.get() && atoi(h->tune.SPARSE.get()) == 4;   // (A/B: the mapping without the padded rows)
+        if ((vmm && !no_pad) || pad_only) {
+            // dense addressing with sparse backing (vmm_back_mbricks): chunks of 2 MiB = 2^14 bricks must hold whole brick rows for
+            // empty chunks to have equal bytes, so a row is padded to a power of two bricks (addresses cost nothing)
+            int64_t p2 = 1;
+            while (p2 < mgx) {
+                p2 <<= 1;
+            }
+            mgx = p2;
+        }
         if (mgx * bgy * bgz >= (1ll << 31) || mgx * bgy >= (1ll << 24) || (int64_t)nx + 2 * mbias >= (1 << 17)) {
             return fail(h, CT_E_INVAL, "volume too large for 32-bit brick indices");
         }
@@ -825,7 +993,7 @@ static int create_impl(const CtScene *s, CtHandle h)
         // when capacity matters.
         bool sparse = (s->flags & CT_FLAG_SPARSE_BRICKS) != 0;
         if (const char *env = h->tune.SPARSE.get()) {
-            sparse = atoi(env) != 0;
+            sparse = atoi(env) == 1;   // (2 = dense addressing with sparse backing, below)
         }
         int src = CT_OK;
         if (e == hipSuccess && e2 == hipSuccess && sparse && s->estimator == CT_EST_MARCH) {
@@ -900,6 +1068,14 @@ static int create_impl(const CtScene *s, CtHandle h)
         if (src != CT_OK) {
             return src;
         }
+#ifdef CT_EXPERIMENTS
+        if (vmm && !sparse) {
+            const int rc = vmm_back_mbricks(h);
+            if (rc != CT_OK) {
+                return rc;
+            }
+        }
+#endif
         d.mbricks = h->d_mbricks;
         d.m_bias_x = mbias;
         d.m_gx = (int32_t)mgx;
@@ -3037,7 +3213,7 @@ extern "C" int ct_debug_memory(CtHandle h, uint64_t out[8])
     out[2] = brick_bytes;                 // shadow-volume apron bricks
     out[3] = h->mbricks_dense_bytes;
     out[4] = h->mbricks_bytes;
-    out[5] = h->dev.m_rows ? 1 : 0;
+    out[5] = h->dev.m_rows ? 1 : (h->vmm.va ? 2 : 0);   // 1 row extents, 2 dense addressing with sparse backing (out[4] = the memory behind it)
     out[6] = h->dev.m_rows ? (size_t)h->dev.brick_gy * h->dev.brick_gz * sizeof(uint2) : 0;
     out[7] = h->dev.m_rows ? (size_t)h->dev.m_cgxy * (size_t)((4 * h->dev.brick_gz + 7) >> h->dev.m_cshift) : 0;
     return CT_OK;

@@ -136,6 +136,10 @@ hipError_t launch_brick_meta(const uint8_t *dist, const uint8_t *majorant, int n
                              int gy, int gz, uint8_t *bricks, hipStream_t stream);
 hipError_t launch_build_mbricks(const uint8_t *texels, int nx, int ny, int nz, int bias_x, int bias, int gx, int gy,
                                 int gz, uint8_t *tmp_a, uint8_t *tmp_b, uint8_t *bricks, hipStream_t stream);
+#ifdef CT_EXPERIMENTS
+hipError_t launch_mbrick_chunk_class(const uint8_t *bricks, int64_t total_bytes, int64_t chunk_bytes, uint4 *out, hipStream_t stream);
+hipError_t launch_mbrick_chunk_quantize(uint8_t *chunk, int64_t chunk_bytes, hipStream_t stream);
+#endif
 hipError_t launch_mbrick_extent(const uint8_t *bricks, int gx, int gy, int gz, uint32_t *row_x0, uint32_t *row_x1, hipStream_t stream);
 hipError_t launch_mbrick_compact(const uint8_t *dense, int gx, int gy, int gz, const uint2 *rows, uint8_t *compact, hipStream_t stream);
 hipError_t launch_coarse_clearance(const uint8_t *dist, int nx, int ny, int nz, int bias, int cshift, int cgx, int cgy, int cgz,

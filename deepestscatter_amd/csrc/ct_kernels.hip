@@ -236,6 +236,90 @@ hipError_t launch_build_mbricks(const uint8_t *texels, int nx, int ny, int nz, i
     return hipGetLastError();
 }
 
+#ifdef CT_EXPERIMENTS
+// ---- march bricks with dense ADDRESSING and sparse BACKING (CT_FLAG_VMM_BRICKS; ct_api.cpp maps the chunks) ---------------
+// Texel bytes: lx < 4; meta bytes: lx == 4 of the base rows ly, lz < 4 (build_mbricks_kernel).  A chunk without a non-zero
+// texel byte is described by its meta bytes alone, and its clearances may be rounded DOWN without changing a result (a
+// smaller clearance only shortens the exact free-space skip): quantised to {0, 4, 8, 16, 32, 64, 127} texels, two such chunks
+// with the same bytes can share one piece of memory.
+CT_DEV uint32_t quantize_meta(uint32_t v)
+{
+    const uint32_t c = v & 0x7fu;
+    const uint32_t q = c >= 127u ? 127u : (c >= 64u ? 64u : (c >= 32u ? 32u : (c >= 16u ? 16u : (c >= 8u ? 8u : (c >= 4u ? 4u : 0u)))));
+    return (v & 0x80u) | q;
+}
+
+// One block per chunk: out[chunk] = (any texel byte non-zero, 0, hash of the quantised meta bytes: low, high word).
+__global__ __launch_bounds__(256) void mbrick_chunk_class_kernel(const uint8_t *__restrict__ bricks, int64_t total_bytes, int64_t chunk_bytes,
+                                                                 uint4 *__restrict__ out)
+{
+    __shared__ uint32_t s_data;
+    __shared__ unsigned long long s_hash;
+    if (threadIdx.x == 0) {
+        s_data = 0;
+        s_hash = 0;
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * chunk_bytes, end = min(base + chunk_bytes, total_bytes);
+    uint32_t data = 0;
+    unsigned long long hsh = 0;   // order-independent: a sum of per-byte mixes of (position in the chunk, quantised value)
+    for (int64_t i = base + (int64_t)threadIdx.x * 4; i < end; i += 256 * 4) {
+        const uint32_t w = *(const uint32_t *)(bricks + i);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t v = (w >> (8 * k)) & 0xffu;
+            const int o = (int)((i + k) & 127);
+            if (o < 125) {
+                const int lx = o % 5, ly = (o / 5) % 5, lz = o / 25;
+                if (lx < 4) {
+                    data |= v;
+                } else if (ly < 4 && lz < 4) {
+                    unsigned long long x = ((unsigned long long)(i + k - base) << 8) | quantize_meta(v);
+                    x *= 0x9e3779b97f4a7c15ull;
+                    x ^= x >> 29;
+                    x *= 0xbf58476d1ce4e5b9ull;
+                    x ^= x >> 32;
+                    hsh += x;
+                }
+            }
+        }
+    }
+    if (data) {
+        atomicOr(&s_data, 1u);
+    }
+    atomicAdd(&s_hash, hsh);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = make_uint4(s_data, 0u, (uint32_t)s_hash, (uint32_t)(s_hash >> 32));
+    }
+}
+
+// Rounds the clearances of a chunk down in place (the chunk that others are mapped onto holds the quantised bytes).
+__global__ void mbrick_chunk_quantize_kernel(uint8_t *__restrict__ chunk, int64_t chunk_bytes)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunk_bytes; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i & 127);
+        const int lx = o % 5, ly = (o / 5) % 5, lz = o / 25;
+        if (o < 125 && lx == 4 && ly < 4 && lz < 4) {
+            chunk[i] = (uint8_t)quantize_meta(chunk[i]);
+        }
+    }
+}
+
+hipError_t launch_mbrick_chunk_class(const uint8_t *bricks, int64_t total_bytes, int64_t chunk_bytes, uint4 *out, hipStream_t stream)
+{
+    const int64_t chunks = (total_bytes + chunk_bytes - 1) / chunk_bytes;
+    hipLaunchKernelGGL(mbrick_chunk_class_kernel, dim3((unsigned)chunks), dim3(256), 0, stream, bricks, total_bytes, chunk_bytes, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mbrick_chunk_quantize(uint8_t *chunk, int64_t chunk_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mbrick_chunk_quantize_kernel, dim3(1024), dim3(256), 0, stream, chunk, chunk_bytes);
+    return hipGetLastError();
+}
+#endif
+
 // ---- sparse march bricks (DevScene::m_rows, m_coarse) ------------------------------------------------------
 // Extent of every brick row: the bricks from the first to the last one with a non-zero texel byte (meta bytes, at
 // lx == 4, do not count).  row_x0 starts at 0xffffffff, row_x1 at 0.

@@ -130,6 +130,14 @@ typedef struct CtScene {
 #define CT_FLAG_SPARSE_BRICKS 4u    /* store the MARCH estimator's density bricks sparsely (only the bricks between the first and
                                        the last non-empty one of every brick row; 9.5x smaller at 1024^3, 20 % slower: for
                                        volumes whose dense bricks would not fit; identical results) */
+#define CT_FLAG_VMM_BRICKS 8u       /* EXPERIMENTS BUILD ONLY (libcloudtrace_exp.so; the product's library answers CT_E_INVAL): measured and
+                                       rejected in round 4 -- memory mapped in 2-MiB pieces is gathered at 0.55 of the hipMalloc rate.
+                                       The same bricks with dense ADDRESSING and sparse BACKING: the dense array's virtual range
+                                       is reserved (hipMemAddressReserve) and only the 2-MiB chunks that hold a non-zero texel,
+                                       or lie within a few texels of one, get memory of their own; every other chunk is mapped
+                                       onto one of a few shared chunks (all-zero texels, a clearance rounded down to 4, 8, 16,
+                                       32, 64 or 127 texels).  The kernel and its address arithmetic are the dense ones;
+                                       identical results (a smaller clearance only makes the exact free-space skip shorter) */
 
 /* Deterministic work counters of everything rendered since create/ct_reset
  * (the algorithmic-bytes figure is built from these). */
@@ -333,7 +341,9 @@ CT_API int ct_buffer_bytes(CtHandle h, int32_t which /*CtBuffer*/, size_t *bytes
  * a progressive render -- (mean, M2, subframe count) IS its whole state, because a sample's seed is (pixel, subframe id): a
  * handle that is given the three continues exactly where the saved one was (the reference's own EXR dumps
  * every 40 subframes, Camera.cpp:211-214, cannot be resumed from -- no variance, no count).  src_bytes must equal
- * ct_buffer_bytes(); other buffers are CT_E_INVAL. */
+ * ct_buffer_bytes(); other buffers are CT_E_INVAL.  With ct_set_stop_when_converged the count that belongs to the buffers
+ * is the FROZEN count (ct_converged_at) once the image has frozen, not ct_subframes, which goes on counting what the host
+ * submits; and both ct_upload and ct_set_subframes release a frozen handle (the image they describe is a new one). */
 CT_API int ct_upload(CtHandle h, int32_t which /*CtBuffer*/, const void *src_host, size_t src_bytes);
 
 /* Raw device pointer of CT_BUF_MEAN / CT_BUF_M2 / CT_BUF_FRAME / CT_BUF_SCREEN, so a caller can
@@ -346,7 +356,8 @@ CT_API int ct_copy_to_device(CtHandle h, int32_t which /*CtBuffer*/, void *dst_d
 /* Enqueued on the handle's stream, not waited for (see ct_render_accumulate_async). */
 CT_API int ct_copy_to_device_async(CtHandle h, int32_t which, void *dst_dev, size_t dst_bytes);
 
-/* Number of subframes accumulated (Camera::subframeId, Camera.h:76). */
+/* Number of subframes submitted so far (Camera::subframeId, Camera.h:76); equals the samples in the buffers unless the image
+ * has frozen (ct_set_stop_when_converged: ct_converged_at then names the count the buffers hold). */
 CT_API int ct_subframes(CtHandle h, uint32_t *count_out);
 
 /* After an external reduction wrote merged data into CT_BUF_MEAN/CT_BUF_M2 (multi-GPU frame
@@ -390,7 +401,8 @@ CT_API int ct_debug_invariants(CtHandle h, uint64_t out[8]);
 /* Device memory of the volume representations (bytes): out[0] raw density texture, out[1] density apron bricks,
  * out[2] shadow-volume apron bricks, out[3] march bricks if stored densely, out[4] march bricks as stored,
  * out[5] = 1 when they are stored sparsely (row extents; CT_FLAG_SPARSE_BRICKS or CT_SPARSE=1), out[6] bytes of the
- * row-extent table, out[7] bytes of the coarse clearance grid. */
+ * row-extent table, out[7] bytes of the coarse clearance grid.  out[5] = 2: dense addressing with sparse backing
+ * (CT_FLAG_VMM_BRICKS or CT_SPARSE=2); out[3] is then the size of the address range and out[4] the memory behind it. */
 CT_API int ct_debug_memory(CtHandle h, uint64_t out[8]);
 
 /* PMC calibration probe (no handle): allocates 2^log2_lines 128-byte lines on `device`, and has one

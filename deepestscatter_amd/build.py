@@ -65,9 +65,11 @@ def build_cli(force: bool = False, verbose: bool = False) -> Path:
 #   exp   -DCT_EXPERIMENTS: the product plus the measured-and-rejected experiments (the two path-exchange kernels of
 #         csrc/ct_exchange.hpp; tests/test_exchange.py and the tools that A/B them)
 #   w8    the DELTA kernel as two 1024-thread blocks per CU, 8 waves per SIMD, 64 VGPRs (round-4 A/B)
+#   nofuse  both estimator kernels with a scatter phase and a march / tracking burst as separate scheduler iterations (round-4 A/B)
 VARIANTS = {
     "exp": ["-DCT_EXPERIMENTS"],
     "w8": ["-DCT_DELTA_THREADS=1024", "-DCT_DELTA_WAVES=8"],
+    "nofuse": ["-DCT_DELTA_FUSE=0", "-DCT_MARCH_FUSE=0"],
 }
 
 

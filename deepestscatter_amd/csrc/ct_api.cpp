@@ -696,7 +696,7 @@ static int create_impl(const CtScene *s, CtHandle h)
         d.march_burst = 2;
         d.burst_scatter = 48;
         d.regen_min = 4;
-        d.scatter_min = 16;
+        d.scatter_min = 12;   // (16 until the tracking burst followed the scatter phase in one iteration; 8 / 12 / 16 / 24 / 32: 5284 / 5290 / 5273 / 5168 / 5104, profiles/r04h, r04i)
     }
     // measured (profiles/README.md): regional queues raise the L2 hit rate from 67 % to 77 % but not
     // the speed (the kernel is bound by the L1 gather rate and by instruction issue, not by L2

@@ -851,6 +851,16 @@ CT_DEV f3 in_scattering_finish(const DevScene &sc, const NeeLoads &n, f3 pos)
 
 enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_BOUNCE = 2 };
 
+// A scatter phase is followed by the march burst in the SAME scheduler iteration -- the lanes it has just redirected march at
+// once -- instead of a pass through the loop's top in between: the scheduler's own instructions (idle / marching / bouncing
+// ballots, the job and drain tests, the queue-empty hint) run once per pair of phases.  Round 4, 512^3 / 1024^2: 3297 -> 3349
+// Msamples/s (+1.6 %; DELTA, where the scheduler is a larger share: 5120 -> 5273, +3.0 %; profiles/r04i).  Schedule only.
+// -DCT_MARCH_FUSE=0 / -DCT_DELTA_FUSE=0 (build --variant nofuse): separate iterations, as until round 3.
+#ifndef CT_MARCH_FUSE
+#define CT_MARCH_FUSE 1
+#endif
+constexpr bool MARCH_FUSE = CT_MARCH_FUSE != 0;
+
 // 1 / max per-axis advance of one march step, in texels (approximate reciprocal is fine: it only
 // sizes a conservative skip, see the free-space skip in the march phase).
 CT_DEV float inv_max_advance(const DevScene &sc, f3 stepv)
@@ -1439,13 +1449,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             }
             w_nee += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(nee_fetched));
         }
-        if (!do_scatter) {
+        // (MARCH_FUSE: the march burst follows a scatter phase in the same scheduler iteration, as in render_delta_kernel)
+        bool track = !do_scatter;
+        uint32_t nm_track = nm;
+        if (do_scatter && MARCH_FUSE) {
+            nm_track = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_MARCH));
+            track = nm_track != 0u;
+        }
+        if (track) {
             // ---------------- march (getNextScatteringEvent, cloud.cuh:87-105) ----------------
             if (STATS) {
                 st_march += 1;
-                st_march_l += nm;
+                st_march_l += nm_track;
             }
-            w_fetch += nm; // every marching lane issues one footprint fetch per burst iteration
+            w_fetch += nm_track; // every marching lane issues one footprint fetch per burst iteration
             // A burst of up to sc.march_burst steps per scheduler visit: the scheduler's own
             // instructions are paid once per burst, and the lanes that collide meanwhile wait for a
             // fuller scatter phase.  The burst ends early when enough lanes wait for the scatter
@@ -1824,6 +1841,10 @@ hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const fl
 #ifndef CT_DELTA_WAVES
 #define CT_DELTA_WAVES 6
 #endif
+#ifndef CT_DELTA_FUSE
+#define CT_DELTA_FUSE 1        // (see CT_MARCH_FUSE)
+#endif
+constexpr bool DELTA_FUSE = CT_DELTA_FUSE != 0;
 constexpr int kDeltaThreads = CT_DELTA_THREADS;
 
 struct Dda {
@@ -2240,13 +2261,23 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                 }
             }
         }
-        if (!do_scatter) {
+        // A scatter phase is followed by the tracking burst in the SAME scheduler iteration -- the lanes it has just redirected
+        // march at once -- instead of a pass through the loop's top in between (round 4: the scheduler's own instructions are a
+        // seventh of the kernel's, and this removes a third of its iterations: 5015 -> 5205 Msamples/s, profiles/r04h; DELTA_FUSE
+        // = 0 restores the separate iterations).  Schedule only: a path's arithmetic does not know when it runs.
+        bool track = !do_scatter;
+        uint32_t nm_track = nm;
+        if (do_scatter && DELTA_FUSE) {
+            nm_track = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_MARCH));
+            track = nm_track != 0u;
+        }
+        if (track) {
             // ---------------- tracking visits: a burst, like the march bursts of render_persistent_kernel ----------------
             if (STATS) {
                 st_march += 1;
-                st_march_l += nm;
-                if (nm) {
-                    st_hist_t[min((nm - 1u) >> 3, 7u)] += 1;
+                st_march_l += nm_track;
+                if (nm_track) {
+                    st_hist_t[min((nm_track - 1u) >> 3, 7u)] += 1;
                 }
                 st_drained_t += drained ? 1u : 0u;
             }

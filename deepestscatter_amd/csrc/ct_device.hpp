@@ -208,6 +208,11 @@ CT_DEV bool in_box(const DevScene &sc, f3 p)
 {
     return p.x >= -0.01f && p.y >= -0.01f && p.z >= -0.01f && p.x <= sc.hx && p.y <= sc.hy && p.z <= sc.hz;
 }
+// The same six comparisons combined on the lane masks (no short circuit: no nested divergent regions).
+CT_DEV bool in_box_flat(const DevScene &sc, f3 p)
+{
+    return (p.x >= -0.01f) & (p.y >= -0.01f) & (p.z >= -0.01f) & (p.x <= sc.hx) & (p.y <= sc.hy) & (p.z <= sc.hz);
+}
 
 // ---- 3-D texture unit ---------------------------------------------------------------------
 // floor / frac of a texel coordinate; v_fract_f32 returns min(x - floor(x), 0x1.fffffep-1)

@@ -1856,12 +1856,13 @@ struct Dda {
 
 CT_DEV bool cell_in_grid(const DevScene &sc, const Dda &d)
 {
-    return (uint32_t)d.bx < (uint32_t)sc.mc_gx && (uint32_t)d.by < (uint32_t)sc.mc_gy && (uint32_t)d.bz < (uint32_t)sc.mc_gz;
+    // (one test, not three nested ones: the three comparisons are combined on the lane masks)
+    return ((uint32_t)d.bx < (uint32_t)sc.mc_gx) & ((uint32_t)d.by < (uint32_t)sc.mc_gy) & ((uint32_t)d.bz < (uint32_t)sc.mc_gz);
 }
 
 CT_DEV uint32_t cell_index(const DevScene &sc, const Dda &d)
 {
-    return __umul24(__umul24((uint32_t)d.bz, (uint32_t)sc.mc_gy) + (uint32_t)d.by, (uint32_t)sc.mc_gx) + (uint32_t)d.bx;
+    return __umul24((uint32_t)d.bz, (uint32_t)(sc.mc_gx * sc.mc_gy)) + __umul24((uint32_t)d.by, (uint32_t)sc.mc_gx) + (uint32_t)d.bx;
 }
 
 // DDA set-up of a flight from `pos` along `dir`.
@@ -2300,10 +2301,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                         const float u = u24_to_float(lcg24(seed));
                         const float dt = -logf_above_one(1.0f - u) * sb.y;
                         const float t_exit = fminf(fminf(dda.tmax.x, dda.tmax.y), dda.tmax.z);
-                        if (dda.t + dt < t_exit) {
-                            dda.t = dda.t + dt;
-                            collide = true;
-                        }
+                        const float t_next = dda.t + dt;
+                        collide = t_next < t_exit;
+                        dda.t = collide ? t_next : dda.t;
                     }
                     if (!collide) {
                         dda_cross(dda, dir);
@@ -2346,21 +2346,21 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                         }
                         real = z * sigma_bar < filter_at(sc, cell, p) * sc.density_multiplier;
                     }
-                    if (real) {
-                        pos = p;
-                        if (in_box(sc, pos)) {
-                            state = ST_BOUNCE;
-                            if (STATS && ba.touched_shadow) {   // (twin bricks: the shadow half lies in the density's line)
-                                const uint32_t line = (uint32_t)((NEE == 2 ? twin_offset_in_grid(sc, p) : apron_offset_in_grid(sc, p)) >> 7);
-                                atomicOr(&(NEE == 2 ? ba.touched_density : ba.touched_shadow)[line >> 5], 1u << (line & 31u));
-                            }
-                            if (NEE == 1) {
-                                nee_raw = load_raw_apron(sc.ibricks + off);
-                            } else if (NEE == 2) {
-                                nee_raw = load_raw_twin(sc.tbricks + off + 64);
-                            }
-                        } else {
-                            ended = true;
+                    // (one divergent region instead of two nested ones: the box test runs under the collision's mask -- the same
+                    // wave instructions as under the real collisions' -- and the position is a select)
+                    const bool bounce = real & in_box_flat(sc, p);
+                    ended = ended | (real & !bounce);
+                    pos = mk3(real ? p.x : pos.x, real ? p.y : pos.y, real ? p.z : pos.z);
+                    if (bounce) {
+                        state = ST_BOUNCE;
+                        if (STATS && ba.touched_shadow) {   // (twin bricks: the shadow half lies in the density's line)
+                            const uint32_t line = (uint32_t)((NEE == 2 ? twin_offset_in_grid(sc, p) : apron_offset_in_grid(sc, p)) >> 7);
+                            atomicOr(&(NEE == 2 ? ba.touched_density : ba.touched_shadow)[line >> 5], 1u << (line & 31u));
+                        }
+                        if (NEE == 1) {
+                            nee_raw = load_raw_apron(sc.ibricks + off);
+                        } else if (NEE == 2) {
+                            nee_raw = load_raw_twin(sc.tbricks + off + 64);
                         }
                     }
                 }

@@ -32,16 +32,9 @@ CT_DEV f3 cross3(f3 a, f3 b)
 {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-// IEEE reciprocal, division and square root of the bounce's arithmetic (correctly rounded: part of the numeric
-// contract).  -DCT_EXPERIMENT_FAST_DIVSQRT maps them to the one-instruction approximations for a TIMING experiment
-// (wrong results): the upper bound of what cheaper correctly-rounded sequences could gain.
-#ifdef CT_EXPERIMENT_FAST_DIVSQRT
-CT_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
-CT_DEV float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-CT_DEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
-CT_DEV float rcp_moderate(float x) { return __builtin_amdgcn_rcpf(x); }
-CT_DEV float sqrt_moderate(float x) { return __builtin_amdgcn_sqrtf(x); }
-#else
+// IEEE reciprocal, division and square root of the bounce's arithmetic (correctly rounded: part of the numeric contract).
+// (Round 2 measured the upper bound of cheaper sequences with a wrong-results build that used the one-instruction
+// approximations: DESIGN.md 4.3 item 8.)
 CT_DEV float rcp_(float x) { return 1.0f / x; }
 CT_DEV float div_(float a, float b) { return a / b; }
 CT_DEV float sqrt_(float x) { return sqrtf(x); }
@@ -65,7 +58,6 @@ CT_DEV float sqrt_moderate(float x)
     // one step is wrong for 60 floats -- mantissa all ones, every other exponent -- so a second one
     return fmaf(fmaf(-s1, s1, x), h, s1);
 }
-#endif
 
 // optix::normalize = v * (1.0f / sqrtf(dot(v,v)))  (OptiX SDK optixu_math_namespace.h)
 CT_DEV f3 normalize3(f3 a)
@@ -312,11 +304,7 @@ CT_DEV uint2 load_footprint_m(const DevScene &sc, int32_t ix, int32_t iy, int32_
     }
     uint2 a, c;
     __builtin_memcpy(&a, p, 8);       // t_lx, t_lx+1 of row ly at bytes 0,1; of row ly+1 at 5,6; M at 4-lx
-#ifdef CT_EXPERIMENT_ONE_LOAD
-    c = a;                            // TIMING EXPERIMENT ONLY (wrong results): what a one-load footprint layout could gain
-#else
     __builtin_memcpy(&c, p + 25, 8);  // the same one z-slice up
-#endif
     meta = __builtin_amdgcn_perm(a.y, a.x, 0x0c0c0c04u - lx);
     uint2 r;
     r.x = __builtin_amdgcn_perm(a.y, a.x, 0x06050100u);
@@ -440,16 +428,12 @@ CT_DEV uint2 fetch_cell_cached(const DevScene &sc, const uint8_t *bricks, f3 p, 
     const uint32_t off = (brick << 7) | local;   // unique while there are fewer than 2^25 bricks: DevScene::nee_cache
     reused = sc.nee_cache != 0u && off == key;
     if (!reused) {
-#ifdef CT_EXPERIMENT_NO_NEE_LOAD
-        cached = make_uint2(off, off >> 3);   // TIMING EXPERIMENT ONLY (wrong radiance, same paths): the shadow-volume fetch for free
-#else
         const uint8_t *q = bricks + (((size_t)brick << 7) | local);
         uint2 a, c;
         __builtin_memcpy(&a, q, 8);
         __builtin_memcpy(&c, q + 25, 8);
         cached.x = __builtin_amdgcn_perm(a.y, a.x, 0x06050100u);
         cached.y = __builtin_amdgcn_perm(c.y, c.x, 0x06050100u);
-#endif
         key = off;
     }
     return cached;

@@ -1199,10 +1199,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0, st_iters = 0, st_first = 0;
     uint32_t st_same_line = 0, st_dup_line = 0, st_prev_line = 0xffffffffu;   // brick-line reuse of the march fetches (STATS)
-#ifdef CT_EXPERIMENT_LINE_REUSE_FREE
-    uint32_t x_prev_line = 0xffffffffu, x_prev_meta = 0;
-    uint2 x_prev_cell = make_uint2(0u, 0u);
-#endif
 
     // ---------------- resume the paths the previous launch suspended ----------------
     // How often this lane's path has been suspended so far (0 = started by this launch).  A path may be handed on while its
@@ -1494,28 +1490,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 }
                 pos = add3(pos, stepv);
                 uint32_t meta;
-#ifdef CT_EXPERIMENT_LINE_REUSE_FREE
-                // TIMING EXPERIMENT ONLY (wrong results): the upper bound of a per-lane brick-line cache -- a fetch that touches
-                // the 128-B line of the lane's previous fetch costs no load at all (no LDS read, no fill, no LDS space either)
-                uint2 cell;
-                {
-                    const float fx = fmaf(pos.x, sc.sx, -0.5f), fy = fmaf(pos.y, sc.sy, -0.5f), fz = fmaf(pos.z, sc.sz, -0.5f);
-                    const uint32_t lx = (uint32_t)(floor_to_int(fx) + sc.m_bias_x), ly = (uint32_t)(floor_to_int(fy) + sc.brick_bias),
-                                   lz = (uint32_t)(floor_to_int(fz) + sc.brick_bias);
-                    const uint32_t line = __umul24(lz >> 2, (uint32_t)sc.m_gxy) + __umul24(ly >> 2, (uint32_t)sc.m_gx) + (__umul24(lx, 43691u) >> 17);
-                    if (line == x_prev_line) {
-                        cell = x_prev_cell;
-                        meta = x_prev_meta;
-                    } else {
-                        cell = fetch_cell_m<SPARSE>(sc, pos, meta);
-                        x_prev_line = line;
-                        x_prev_cell = cell;
-                        x_prev_meta = meta;
-                    }
-                }
-#else
                 const uint2 cell = fetch_cell_m<SPARSE>(sc, pos, meta);
-#endif
                 dfree = meta & 0x7fu;
                 c_dl += 1;
                 work += 1u;

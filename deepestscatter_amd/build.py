@@ -69,7 +69,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> Path:
 VARIANTS = {
     "exp": ["-DCT_EXPERIMENTS"],
     "w8": ["-DCT_DELTA_THREADS=1024", "-DCT_DELTA_WAVES=8"],
-    "nofuse": ["-DCT_DELTA_FUSE=0", "-DCT_MARCH_FUSE=0"],
+    "nofuse": ["-DCT_DELTA_FUSE=0", "-DCT_MARCH_FUSE=0", "-DCT_DELTA_CHECK_EVERY=1"],
 }
 
 

@@ -1820,6 +1820,10 @@ hipError_t launch_descriptors(const DevScene &sc, const MipPyramid &mp, const fl
 #define CT_DELTA_FUSE 1        // (see CT_MARCH_FUSE)
 #endif
 constexpr bool DELTA_FUSE = CT_DELTA_FUSE != 0;
+#ifndef CT_DELTA_CHECK_EVERY
+#define CT_DELTA_CHECK_EVERY 2   // (5303 -> 5324 Msamples/s against 1, profiles/r04o; -DCT_DELTA_CHECK_EVERY=1: after every visit, as until round 4)
+#endif
+constexpr uint32_t DELTA_CHECK_EVERY = CT_DELTA_CHECK_EVERY;
 constexpr int kDeltaThreads = CT_DELTA_THREADS;
 
 struct Dda {
@@ -2359,15 +2363,24 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
             if (--burst == 0u) {
                 break;
             }
+            // (CT_DELTA_CHECK_EVERY = 2: the burst's end conditions are looked at after every second visit only -- with bursts of
+            // two, never: a visit without marching lanes is a no-op, and after one visit of a full wave 26 lanes wait for the
+            // scatter phase, not the 48 that end a burst)
+            if (DELTA_CHECK_EVERY > 1 && !STATS && (burst % DELTA_CHECK_EVERY) != 0u) {
+                continue;
+            }
             const uint32_t m_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_MARCH));
             const uint32_t b_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_BOUNCE));
-            if (m_now == 0u || b_now >= sc.burst_scatter || 64u - m_now - b_now >= sc.burst_idle) {
+            if ((DELTA_CHECK_EVERY == 1 || (burst % DELTA_CHECK_EVERY) == 0u) &&
+                (m_now == 0u || b_now >= sc.burst_scatter || 64u - m_now - b_now >= sc.burst_idle)) {
                 break;
             }
             if (STATS) {
                 st_march += 1;
                 st_march_l += m_now;
-                st_hist_t[min((m_now - 1u) >> 3, 7u)] += 1;
+                if (m_now) {
+                    st_hist_t[min((m_now - 1u) >> 3, 7u)] += 1;
+                }
                 st_drained_t += drained ? 1u : 0u;
             }
             }

@@ -32,6 +32,9 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# (multi-process GPU work on this pool: the host driver only supports dmabuf IPC; without this RCCL's peer mappings fail with
+# hipIpcGetMemHandle: invalid argument.  The launcher normally exports it; a bare shell may not.)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 MEASURED_COPY_GBS = 6290.0          # the same guide: float4 copy, 79 % of spec

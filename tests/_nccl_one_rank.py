@@ -18,6 +18,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 def main():
     merge, port = sys.argv[1], sys.argv[2]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import deepestscatter_amd as ds

@@ -79,7 +79,9 @@ constexpr int kGuideN = 4096;         // buckets of the CDF guide table
 constexpr float kFracMax = 0x1.fffffep-1f;
 constexpr int kBrick = 4;             // texels per edge of a free-space brick
 constexpr int kBrickShift = 2;
-constexpr int kMajCellsMax = 40960;   // cells of the DELTA majorant grid (one byte each, LDS-resident)
+constexpr int kMajCellsMax = 43008;   // cells of the DELTA majorant grid (one byte each, LDS-resident): 42 KiB -- with the codes and the
+                                      // tables 80400 of the 81920 bytes a block may use with two blocks per CU; 40960 until round 4,
+                                      // which left a 256^3 volume (35^3 = 42875 cells of 8 texels) with 16-texel cells
 
 // All uniforms of the path: the OptiX variable scopes of SURVEY section 8b, flattened.
 struct DevScene {

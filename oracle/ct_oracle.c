@@ -436,7 +436,7 @@ static Event next_scattering_event(const Ctx *c, float optical_distance, v3 pos,
  *   collision.  Unbiased for the trilinear medium; the reference's march is an O(step)-biased
  *   estimator of the same free-flight distribution.
  * ------------------------------------------------------------------------------------------ */
-#define ORC_MAJ_CELLS_MAX 40960
+#define ORC_MAJ_CELLS_MAX 43008   /* (42 KiB: what the product's LDS holds beside its tables; a 256^3 volume gets 8-texel cells: 35^3) */
 
 /* out = { bias, cells x, cells y, cells z, shift } */
 ORC_API void orc_majorant_grid(const uint32_t dims[3], float sample_step, int32_t out[5])

@@ -852,32 +852,89 @@ static int create_impl(const CtScene *s, CtHandle h)
                                     h->d_dbricks, h->stream));
     }
     if (s->estimator == CT_EST_DELTA) {
-        // majorant cells of the DELTA grid (orc_majorant_grid / orc_build_majorants in the oracle): cells of
-        // 2^shift texels over [-bias, n + bias), the smallest shift whose grid fits the kernel's LDS array
-        int shift = 2;
-        int64_t cgx, cgy, cgz;
-        for (;; shift++) {
-            const int64_t c = 1ll << shift;
-            cgx = ((int64_t)nx + 2 * bbias + c - 1) >> shift;
-            cgy = ((int64_t)ny + 2 * bbias + c - 1) >> shift;
-            cgz = ((int64_t)nz + 2 * bbias + c - 1) >> shift;
-            if (cgx * cgy * cgz <= kMajCellsMax) {
+        // Majorant cells of the DELTA grid (orc_majorant_grid / orc_build_majorants in the oracle, same rule).  A VIRTUAL grid of
+        // cubic cells of C texels covers [-bias, n + bias); stored -- and copied to LDS by every block -- is only the box of cells
+        // that can have a non-zero majorant: per axis the cells whose clamped read interval [clamp(lo - 1), clamp(lo + C + 1)] meets
+        // the bounding interval of the non-zero texels.  C = the smallest value >= 4 whose box fits the kernel's LDS array: the
+        // benchmark cloud at 512^3 gets 10-texel cells where a grid over the whole volume allowed 16 (round 4).
+        const int32_t n[3] = { (int32_t)nx, (int32_t)ny, (int32_t)nz };
+        int32_t lo[3] = { n[0], n[1], n[2] }, hi[3] = { -1, -1, -1 };
+        {
+            const uint8_t *t = s->density_host;
+            for (int32_t z = 0; z < n[2]; z++) {
+                for (int32_t y = 0; y < n[1]; y++) {
+                    const uint8_t *row = t + ((size_t)z * n[1] + y) * n[0];
+                    int32_t x0 = 0, x1 = n[0] - 1;
+                    while (x0 <= x1 && row[x0] == 0) {
+                        x0++;
+                    }
+                    if (x0 > x1) {
+                        continue;
+                    }
+                    while (row[x1] == 0) {
+                        x1--;
+                    }
+                    lo[0] = std::min(lo[0], x0);
+                    hi[0] = std::max(hi[0], x1);
+                    lo[1] = std::min(lo[1], y);
+                    hi[1] = std::max(hi[1], y);
+                    lo[2] = std::min(lo[2], z);
+                    hi[2] = std::max(hi[2], z);
+                }
+            }
+        }
+        int32_t C = 4, origin[3] = { 0, 0, 0 }, stored[3] = { 1, 1, 1 }, virt[3] = { 1, 1, 1 };
+        for (;; C++) {
+            int64_t cells = 1;
+            for (int a = 0; a < 3; a++) {
+                const int32_t v = (n[a] + 2 * bbias + C - 1) / C;
+                int32_t c0 = v, c1 = -1;
+                for (int32_t c = 0; c < v; c++) {
+                    const int32_t r0 = std::min(std::max(C * c - bbias - 1, 0), n[a] - 1), r1 = std::min(std::max(C * c - bbias + C + 1, 0), n[a] - 1);
+                    if (r0 <= hi[a] && r1 >= lo[a]) {
+                        c0 = std::min(c0, c);
+                        c1 = c;
+                    }
+                }
+                if (c1 < c0) {   // an empty volume: one stored cell, whose majorant will be 0
+                    c0 = c1 = 0;
+                }
+                origin[a] = c0;
+                stored[a] = c1 - c0 + 1;
+                virt[a] = v;
+                cells *= (int64_t)stored[a];
+            }
+            if (cells <= kMajCellsMax) {
                 break;
             }
         }
-        const size_t cells = (size_t)(cgx * cgy * cgz);
+        // x / C as (x * div) >> 20 for every texel index of the grid (dda_begin): checked, not argued
+        const int32_t div = (int32_t)(((1u << 20) + (uint32_t)C - 1u) / (uint32_t)C);
+        for (int32_t x = 0; x < (std::max({ virt[0], virt[1], virt[2] }) + 1) * C; x++) {
+            if ((int32_t)(((uint32_t)x * (uint32_t)div) >> 20) != x / C || (uint64_t)x * (uint64_t)div >= (1ull << 32)) {
+                return fail(h, CT_E_INVAL, "volume too large for the majorant grid's index arithmetic");
+            }
+        }
+        const size_t cells = (size_t)stored[0] * stored[1] * stored[2];
         HIPCHK(h, dmalloc(&h->d_maj_cells, (cells + 3) & ~(size_t)3)); // the kernel copies whole words
         HIPCHK(h, hipMemsetAsync(h->d_maj_cells, 0, (cells + 3) & ~(size_t)3, h->stream));
         HIPCHK(h, dmalloc(&h->d_maj_codes, (cells + 3) & ~(size_t)3));
         HIPCHK(h, hipMemsetAsync(h->d_maj_codes, 0, (cells + 3) & ~(size_t)3, h->stream));
-        HIPCHK(h, launch_majorant_cells(h->d_density, nx, ny, nz, bbias, shift, (int)cgx, (int)cgy, (int)cgz, h->d_maj_cells,
+        HIPCHK(h, launch_majorant_cells(h->d_density, nx, ny, nz, bbias, C, origin, stored[0], stored[1], stored[2], h->d_maj_cells,
                                         h->d_maj_codes, h->stream));
         d.maj_cells = h->d_maj_cells;
         d.maj_codes = h->d_maj_codes;
-        d.mc_shift = shift;
-        d.mc_gx = (int32_t)cgx;
-        d.mc_gy = (int32_t)cgy;
-        d.mc_gz = (int32_t)cgz;
+        d.mc_cell = C;
+        d.mc_div = div;
+        d.mc_gx = stored[0];
+        d.mc_gy = stored[1];
+        d.mc_gz = stored[2];
+        d.mc_x0 = origin[0];
+        d.mc_y0 = origin[1];
+        d.mc_z0 = origin[2];
+        d.mc_vx = virt[0];
+        d.mc_vy = virt[1];
+        d.mc_vz = virt[2];
     }
     // which of the volume's six boundary layers are empty (launch_inscatter: a march that leaves through one of those is over)
     uint32_t zero_faces = 0;

@@ -125,10 +125,9 @@ struct DevScene {
     const uint2 *m_rows;
     const uint8_t *m_coarse;
     int32_t m_cshift, m_cgx, m_cgxy;
-    // The DELTA estimator's majorants: one byte per cubic cell of 2^mc_shift texels over the texel range
-    // [-brick_bias, n + brick_bias) per axis, x-fastest.  mc_shift is the smallest value >= 2 for which the grid
-    // has at most kMajCellsMax cells, so that every block keeps the whole grid in LDS and a flight crosses cells
-    // without touching memory (oracle/ct_oracle.c, DELTA header: same grid, same majorants).
+    // The DELTA estimator's majorants: one byte per stored cubic cell of mc_cell texels, x-fastest.  mc_cell is the smallest
+    // value >= 4 for which the stored box has at most kMajCellsMax cells, so that every block keeps it in LDS and a flight
+    // crosses cells without touching memory (oracle/ct_oracle.c, orc_majorant_grid: same grid, same majorants).
     // Twin bricks (DELTA estimator): one 128-byte line per 3x3x3 base texels.  Bytes 0..63 = the 4x4x4 DENSITY texels
     // [3b, 3b+3]^3 (clamp-to-edge applied) at byte lz*16 + ly*4 + lx, bytes 64..127 = the SHADOW volume's texels at the same
     // places.  A Woodcock collision is a point: the density lookup that decides it (cloud.cuh:58-62) and the NEE lookup of the
@@ -142,7 +141,10 @@ struct DevScene {
     uint32_t delta_nee;         // render_delta_kernel<.., NEE>: 0, 1 or 2 (2 only with tbricks)
     const uint8_t *maj_cells;
     const uint8_t *maj_codes;   // per cell q = min(3, 4*min/max) of its texels: texel value (q*M) >> 2 bounds the cell from below
-    int32_t mc_shift, mc_gx, mc_gy, mc_gz;
+    // (round 4) A VIRTUAL grid of mc_vx x mc_vy x mc_vz cubic cells of mc_cell texels (any size >= 4) covers [-brick_bias, n + brick_bias);
+    // only the box of cells around the non-zero texels is stored: mc_gx x mc_gy x mc_gz cells from virtual cell (mc_x0, mc_y0, mc_z0).
+    // A virtual cell outside the box has majorant 0.  mc_div: x / mc_cell == (x * mc_div) >> 20 for every texel index of the grid.
+    int32_t mc_cell, mc_div, mc_gx, mc_gy, mc_gz, mc_x0, mc_y0, mc_z0, mc_vx, mc_vy, mc_vz;
     int32_t m_bias_x;        // x bias of the 3-texel brick columns (multiple of 3)
     int32_t m_gx, m_gxy;     // bricks per row / per slice of mbricks (y and z use brick_gy/gz, brick_bias)
     int32_t nx, ny, nz;    // texels

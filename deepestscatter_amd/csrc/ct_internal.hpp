@@ -130,7 +130,7 @@ hipError_t launch_build_twin_bricks(const uint8_t *density, const uint8_t *shado
                                     uint8_t *bricks, hipStream_t stream);
 hipError_t launch_build_dist(const uint8_t *texels, int nx, int ny, int nz, int bias, int gx, int gy, int gz,
                              uint8_t *dist, uint8_t *scratch, uint8_t *majorant, hipStream_t stream);
-hipError_t launch_majorant_cells(const uint8_t *texels, int nx, int ny, int nz, int bias, int shift, int gx, int gy, int gz,
+hipError_t launch_majorant_cells(const uint8_t *texels, int nx, int ny, int nz, int bias, int cell, const int origin[3], int gx, int gy, int gz,
                                  uint8_t *out, uint8_t *out_codes, hipStream_t stream);
 hipError_t launch_brick_meta(const uint8_t *dist, const uint8_t *majorant, int nx, int ny, int nz, int bias, int gx,
                              int gy, int gz, uint8_t *bricks, hipStream_t stream);

@@ -1833,16 +1833,27 @@ struct Dda {
     int32_t bx, by, bz;
 };
 
+// Is the flight's cell one of the STORED cells (the box around the cloud)?  A flight that leaves the box is over: a straight
+// line does not come back into a box, and outside it every cell is empty (no random number is drawn there).
 CT_DEV bool cell_in_grid(const DevScene &sc, const Dda &d)
 {
     // (one test, not three nested ones: the three comparisons are combined on the lane masks)
-    return ((uint32_t)d.bx < (uint32_t)sc.mc_gx) & ((uint32_t)d.by < (uint32_t)sc.mc_gy) & ((uint32_t)d.bz < (uint32_t)sc.mc_gz);
+    return ((uint32_t)(d.bx - sc.mc_x0) < (uint32_t)sc.mc_gx) & ((uint32_t)(d.by - sc.mc_y0) < (uint32_t)sc.mc_gy) &
+           ((uint32_t)(d.bz - sc.mc_z0) < (uint32_t)sc.mc_gz);
+}
+
+CT_DEV bool cell_in_virtual_grid(const DevScene &sc, const Dda &d)
+{
+    return ((uint32_t)d.bx < (uint32_t)sc.mc_vx) & ((uint32_t)d.by < (uint32_t)sc.mc_vy) & ((uint32_t)d.bz < (uint32_t)sc.mc_vz);
 }
 
 CT_DEV uint32_t cell_index(const DevScene &sc, const Dda &d)
 {
-    return __umul24((uint32_t)d.bz, (uint32_t)(sc.mc_gx * sc.mc_gy)) + __umul24((uint32_t)d.by, (uint32_t)sc.mc_gx) + (uint32_t)d.bx;
+    return __umul24((uint32_t)(d.bz - sc.mc_z0), (uint32_t)(sc.mc_gx * sc.mc_gy)) + __umul24((uint32_t)(d.by - sc.mc_y0), (uint32_t)sc.mc_gx) +
+           (uint32_t)(d.bx - sc.mc_x0);
 }
+
+CT_DEV void dda_cross(Dda &d, f3 dir);
 
 // DDA set-up of a flight from `pos` along `dir`.
 CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
@@ -1851,11 +1862,12 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
     d.t = 0.0f;
     const float tpx = fmaf(pos.x, sc.sx, -0.5f), tpy = fmaf(pos.y, sc.sy, -0.5f), tpz = fmaf(pos.z, sc.sz, -0.5f);
     const float vx = dir.x * sc.sx, vy = dir.y * sc.sy, vz = dir.z * sc.sz;
-    d.bx = (floor_to_int(tpx) + sc.brick_bias) >> sc.mc_shift;
-    d.by = (floor_to_int(tpy) + sc.brick_bias) >> sc.mc_shift;
-    d.bz = (floor_to_int(tpz) + sc.brick_bias) >> sc.mc_shift;
+    // texel index / cell size by a multiplication (exact for every index of the grid: checked when the grid is made)
+    d.bx = (int32_t)(__umul24((uint32_t)(floor_to_int(tpx) + sc.brick_bias), (uint32_t)sc.mc_div) >> 20);
+    d.by = (int32_t)(__umul24((uint32_t)(floor_to_int(tpy) + sc.brick_bias), (uint32_t)sc.mc_div) >> 20);
+    d.bz = (int32_t)(__umul24((uint32_t)(floor_to_int(tpz) + sc.brick_bias), (uint32_t)sc.mc_div) >> 20);
     const float inf = __uint_as_float(0x7f800000u);
-    const float edge = (float)(1 << sc.mc_shift);
+    const float edge = (float)sc.mc_cell;
     // One division per axis and NO branch around it: the lanes of a wave disagree about the sign of V, so an
     // if / else-if with a division in each arm made every wave execute both (six IEEE divisions per set-up).  The values
     // are the oracle's: inv = 1 / V; V > 0: tmax = (upper bound - tp) * inv, tdelta = edge * inv; V < 0: tmax = (lower
@@ -1868,7 +1880,7 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
     const float v_min = fminf(fminf(fabsf(vx), fabsf(vy)), fabsf(vz)), v_max = fmaxf(fmaxf(fabsf(vx), fabsf(vy)), fabsf(vz));
     const bool moderate = v_min >= 0x1p-60f && v_max <= 0x1p60f;
     auto axis = [&](int32_t B, float TP, float V, float inv, float &TMAX, float &TDELTA) {
-        const int32_t bound = ((B + (V > 0.0f ? 1 : 0)) << sc.mc_shift) - sc.brick_bias;
+        const int32_t bound = (int32_t)__umul24((uint32_t)(B + (V > 0.0f ? 1 : 0)), (uint32_t)sc.mc_cell) - sc.brick_bias;
         const bool moving = V != 0.0f;
         TMAX = moving ? ((float)bound - TP) * inv : inf;
         TDELTA = moving ? edge * fabsf(inv) : inf;
@@ -1881,6 +1893,12 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
         axis(d.bx, tpx, vx, rcp_(vx), d.tmax.x, d.tdelta.x);
         axis(d.by, tpy, vy, rcp_(vy), d.tmax.y, d.tdelta.y);
         axis(d.bz, tpz, vz, rcp_(vz), d.tmax.z, d.tdelta.z);
+    }
+    // A flight that starts OUTSIDE the stored box (a primary ray that enters the volume beside the cloud; a scatter position that
+    // rounds into the neighbour of a cell on the box's face) crosses the empty virtual cells up to it, with the crossings' own
+    // arithmetic -- the oracle's flight steps through the same cells one by one -- or leaves the virtual grid without meeting it.
+    while (cell_in_virtual_grid(sc, d) && !cell_in_grid(sc, d)) {
+        dda_cross(d, dir);
     }
 }
 
@@ -1930,15 +1948,16 @@ __global__ __launch_bounds__(256) void primary_advance_delta_kernel(DevScene sc,
     advance[4 * p + 3] = make_float4(__int_as_float(d.bz), 0.f, 0.f, 0.f);
 }
 
-// Majorant of every cell of the DELTA grid: the max of the texels [lo-1, lo+C+1]^3 (clamped), and the 2-bit code
-// of their min (q = min(3, 4*min/max)); one block per cell (orc_build_majorants in the oracle).
+// Majorant of every STORED cell of the DELTA grid: the max of the texels [lo-1, lo+C+1]^3 (clamped), and the 2-bit code
+// of their min (q = min(3, 4*min/max)); one block per cell, cell (cx, cy, cz) = virtual cell origin + (cx, cy, cz)
+// (orc_build_majorants in the oracle).
 __global__ __launch_bounds__(256) void majorant_cells_kernel(const uint8_t *__restrict__ texels, int nx, int ny, int nz, int bias,
-                                                             int shift, int gx, int gy, uint8_t *__restrict__ out,
+                                                             int C, int ox, int oy, int oz, int gx, int gy, uint8_t *__restrict__ out,
                                                              uint8_t *__restrict__ out_codes)
 {
     const int cx = blockIdx.x, cy = blockIdx.y, cz = blockIdx.z;
-    const int C = 1 << shift, w = C + 3;
-    const int x0 = C * cx - bias - 1, y0 = C * cy - bias - 1, z0 = C * cz - bias - 1;
+    const int w = C + 3;
+    const int x0 = C * (cx + ox) - bias - 1, y0 = C * (cy + oy) - bias - 1, z0 = C * (cz + oz) - bias - 1;
     uint32_t m = 0, lo = 255;
     for (int i = threadIdx.x; i < w * w * w; i += 256) {
         const int lx = i % w, ly = (i / w) % w, lz = i / (w * w);
@@ -1963,11 +1982,11 @@ __global__ __launch_bounds__(256) void majorant_cells_kernel(const uint8_t *__re
     }
 }
 
-hipError_t launch_majorant_cells(const uint8_t *texels, int nx, int ny, int nz, int bias, int shift, int gx, int gy, int gz,
+hipError_t launch_majorant_cells(const uint8_t *texels, int nx, int ny, int nz, int bias, int cell, const int origin[3], int gx, int gy, int gz,
                                  uint8_t *out, uint8_t *out_codes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(majorant_cells_kernel, dim3(gx, gy, gz), dim3(256), 0, stream, texels, nx, ny, nz, bias, shift, gx, gy, out,
-                       out_codes);
+    hipLaunchKernelGGL(majorant_cells_kernel, dim3(gx, gy, gz), dim3(256), 0, stream, texels, nx, ny, nz, bias, cell, origin[0], origin[1],
+                       origin[2], gx, gy, out, out_codes);
     return hipGetLastError();
 }
 

@@ -227,7 +227,7 @@ typedef struct OrcScene {
      * over per-brick majorants; NOT in the reference -- BASELINE.json north_star / SURVEY section 7.6) */
     int32_t estimator;
     const uint8_t *majorant;       /* orc_build_majorants(), needed for DELTA */
-    int32_t maj_bias, maj_gx, maj_gy, maj_gz, maj_shift;
+    int32_t maj_bias, maj_gx, maj_gy, maj_gz, maj_cell; /* stored cells per axis; cell edge in texels (orc_majorant_grid) */
     const uint8_t *maj_codes;      /* orc_build_majorants(): per cell q = min(3, 4*min/max), see delta_flight */
     /* Lazy shadow volume (NULL = `inscatter` is complete).  Otherwise one byte per texel, 0 = `inscatter` does not hold
      * that texel yet: sampleInScatter evaluates inScatter (inScatter.cu:40-66) for the missing ones of its footprint
@@ -235,6 +235,9 @@ typedef struct OrcScene {
      * 512^3 / 1024^3 window test check the product's whole shadow-volume kernel where it matters without a CPU pass
      * over 1e8-1e9 texels.  `inscatter` must then be writable. */
     uint8_t *inscatter_valid;
+    /* DELTA grid, continued: the stored cells are the sub-range [maj_origin, maj_origin + (maj_gx, maj_gy, maj_gz)) of a virtual
+     * grid of maj_virtual cells over the texel range [-bias, n + bias); a virtual cell outside the stored range has majorant 0 */
+    int32_t maj_origin[3], maj_virtual[3];
 } OrcScene;
 
 typedef struct OrcCounters {
@@ -259,7 +262,7 @@ typedef struct {
     int32_t mode;
     int32_t estimator;
     const uint8_t *maj, *maj_codes;
-    int32_t maj_bias, maj_gx, maj_gy, maj_gz, maj_shift;
+    int32_t maj_bias, maj_gx, maj_gy, maj_gz, maj_cell, maj_x0, maj_y0, maj_z0, maj_vx, maj_vy, maj_vz;
     uint8_t *ins_valid;      /* lazy shadow volume: see OrcScene::inscatter_valid */
     float sigma_global;      /* estimator 2: majorant of the whole volume */
 } Ctx;
@@ -305,7 +308,13 @@ static void ctx_init(Ctx *c, const OrcScene *s)
     c->maj_gx = s->maj_gx;
     c->maj_gy = s->maj_gy;
     c->maj_gz = s->maj_gz;
-    c->maj_shift = s->maj_shift;
+    c->maj_cell = s->maj_cell;
+    c->maj_x0 = s->maj_origin[0];
+    c->maj_y0 = s->maj_origin[1];
+    c->maj_z0 = s->maj_origin[2];
+    c->maj_vx = s->maj_virtual[0];
+    c->maj_vy = s->maj_virtual[1];
+    c->maj_vz = s->maj_virtual[2];
     c->maj_codes = s->maj_codes;
     c->ins_valid = s->inscatter_valid;
     c->sigma_global = 0.0f;
@@ -438,43 +447,86 @@ static Event next_scattering_event(const Ctx *c, float optical_distance, v3 pos,
  * ------------------------------------------------------------------------------------------ */
 #define ORC_MAJ_CELLS_MAX 43008   /* (42 KiB: what the product's LDS holds beside its tables; a 256^3 volume gets 8-texel cells: 35^3) */
 
-/* out = { bias, cells x, cells y, cells z, shift } */
-ORC_API void orc_majorant_grid(const uint32_t dims[3], float sample_step, int32_t out[5])
+/* The grid (round 4).  A VIRTUAL grid of cubic cells of C texels covers the texel range [-bias, n + bias) per axis, cell c
+ * the base texels [C*c - bias, C*c - bias + C - 1]; of it only the cells that can have a non-zero majorant are STORED: per axis
+ * the range of cells whose clamped read interval [clamp(lo - 1), clamp(lo + C + 1)] meets the bounding interval of the non-zero
+ * texels (a product of three ranges: a box of cells around the cloud).  C is the smallest value >= 4 for which the stored box
+ * has at most ORC_MAJ_CELLS_MAX cells -- 12-texel cells for the benchmark cloud at 512^3, whose box is 0.9 x 0.6 x 0.8 of the
+ * volume, where the whole volume allowed 16.  A virtual cell outside the stored box has majorant 0 by construction.
+ * out = { bias, C, origin x, y, z (virtual cell of the first stored one), stored cells x, y, z, virtual cells x, y, z } */
+ORC_API void orc_majorant_grid(const uint8_t *texels, const uint32_t dims[3], float sample_step, int32_t out[11])
 {
     const float m = (float)(dims[0] > dims[1] ? (dims[0] > dims[2] ? dims[0] : dims[2]) : (dims[1] > dims[2] ? dims[1] : dims[2]));
     const int32_t apron = (int32_t)ceilf((0.01f + 8.0f * sample_step) * m + 0.5f) + 1;
     const int32_t bias = ((apron + 3) / 4) * 4;
-    int32_t shift = 2;
-    for (;; shift++) {
-        const int64_t c = (int64_t)1 << shift;
-        const int64_t gx = ((int64_t)dims[0] + 2 * bias + c - 1) >> shift, gy = ((int64_t)dims[1] + 2 * bias + c - 1) >> shift,
-                      gz = ((int64_t)dims[2] + 2 * bias + c - 1) >> shift;
-        if (gx * gy * gz <= ORC_MAJ_CELLS_MAX) {
-            out[1] = (int32_t)gx;
-            out[2] = (int32_t)gy;
-            out[3] = (int32_t)gz;
-            break;
+    const int32_t n[3] = { (int32_t)dims[0], (int32_t)dims[1], (int32_t)dims[2] };
+    /* bounding interval of the non-zero texels per axis (lo > hi: none) */
+    int32_t lo[3] = { n[0], n[1], n[2] }, hi[3] = { -1, -1, -1 };
+    for (int32_t z = 0; z < n[2]; z++) {
+        for (int32_t y = 0; y < n[1]; y++) {
+            const uint8_t *row = texels + ((size_t)z * n[1] + y) * n[0];
+            int32_t x0 = 0, x1 = n[0] - 1;
+            while (x0 <= x1 && row[x0] == 0) {
+                x0++;
+            }
+            if (x0 > x1) {
+                continue;
+            }
+            while (row[x1] == 0) {
+                x1--;
+            }
+            lo[0] = x0 < lo[0] ? x0 : lo[0];
+            hi[0] = x1 > hi[0] ? x1 : hi[0];
+            lo[1] = y < lo[1] ? y : lo[1];
+            hi[1] = y > hi[1] ? y : hi[1];
+            lo[2] = z < lo[2] ? z : lo[2];
+            hi[2] = z > hi[2] ? z : hi[2];
         }
     }
     out[0] = bias;
-    out[4] = shift;
+    for (int32_t C = 4;; C++) {
+        int64_t cells = 1;
+        for (int a = 0; a < 3; a++) {
+            const int32_t v = (n[a] + 2 * bias + C - 1) / C;
+            int32_t c0 = v, c1 = -1;
+            for (int32_t c = 0; c < v; c++) {
+                const int32_t r0 = clampi(C * c - bias - 1, 0, n[a] - 1), r1 = clampi(C * c - bias + C + 1, 0, n[a] - 1);
+                if (r0 <= hi[a] && r1 >= lo[a]) {
+                    c0 = c < c0 ? c : c0;
+                    c1 = c;
+                }
+            }
+            if (c1 < c0) { /* an empty volume: one stored cell (its majorant will be 0) */
+                c0 = c1 = 0;
+            }
+            out[2 + a] = c0;
+            out[5 + a] = c1 - c0 + 1;
+            out[8 + a] = v;
+            cells *= (int64_t)(c1 - c0 + 1);
+        }
+        if (cells <= ORC_MAJ_CELLS_MAX) {
+            out[1] = C;
+            return;
+        }
+    }
 }
 
-ORC_API void orc_build_majorants(const uint8_t *texels, const uint32_t dims[3], int32_t bias, int32_t shift, int32_t gx,
-                                 int32_t gy, int32_t gz, uint8_t *out, uint8_t *out_codes)
+/* Majorants and lower-bound codes of the stored cells: cell (cx, cy, cz) of the stored box is virtual cell origin + (cx, cy, cz). */
+ORC_API void orc_build_majorants(const uint8_t *texels, const uint32_t dims[3], int32_t bias, int32_t C, const int32_t origin[3],
+                                 int32_t gx, int32_t gy, int32_t gz, uint8_t *out, uint8_t *out_codes)
 {
     const int32_t nx = (int32_t)dims[0], ny = (int32_t)dims[1], nz = (int32_t)dims[2];
-    const int32_t C = 1 << shift;
 #pragma omp parallel for schedule(static)
     for (int32_t cz = 0; cz < gz; cz++) {
         for (int32_t cy = 0; cy < gy; cy++) {
             for (int32_t cx = 0; cx < gx; cx++) {
+                const int32_t x0 = C * (cx + origin[0]) - bias, y0 = C * (cy + origin[1]) - bias, z0 = C * (cz + origin[2]) - bias;
                 uint8_t m = 0, lo = 255;
-                for (int32_t z = C * cz - bias - 1; z <= C * cz - bias + C + 1; z++) {
+                for (int32_t z = z0 - 1; z <= z0 + C + 1; z++) {
                     const int32_t zc = clampi(z, 0, nz - 1);
-                    for (int32_t y = C * cy - bias - 1; y <= C * cy - bias + C + 1; y++) {
+                    for (int32_t y = y0 - 1; y <= y0 + C + 1; y++) {
                         const int32_t yc = clampi(y, 0, ny - 1);
-                        for (int32_t x = C * cx - bias - 1; x <= C * cx - bias + C + 1; x++) {
+                        for (int32_t x = x0 - 1; x <= x0 + C + 1; x++) {
                             const uint8_t v = texels[((size_t)zc * ny + yc) * nx + clampi(x, 0, nx - 1)];
                             m = v > m ? v : m;
                             lo = v < lo ? v : lo;
@@ -497,19 +549,19 @@ static Event delta_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCount
     const float v[3] = { dir.x * c->density.sx, dir.y * c->density.sy, dir.z * c->density.sz };
     int32_t b[3], step[3];
     float tmax[3], tdelta[3];
-    const float edge = (float)(1 << c->maj_shift);
+    const float edge = (float)c->maj_cell;
     for (int a = 0; a < 3; a++) {
         const int32_t cell = (int32_t)floorf(tp[a]) + c->maj_bias;
-        b[a] = cell >> c->maj_shift;
+        b[a] = cell / c->maj_cell;   /* (cell >= 0: the bias covers every position a flight can start from) */
         if (v[a] > 0.0f) {
             const float inv = 1.0f / v[a]; /* one division per axis; the products below are what the kernel computes */
             step[a] = 1;
-            tmax[a] = ((float)(((b[a] + 1) << c->maj_shift) - c->maj_bias) - tp[a]) * inv;
+            tmax[a] = ((float)((b[a] + 1) * c->maj_cell - c->maj_bias) - tp[a]) * inv;
             tdelta[a] = edge * inv;
         } else if (v[a] < 0.0f) {
             const float inv = 1.0f / v[a];
             step[a] = -1;
-            tmax[a] = ((float)((b[a] << c->maj_shift) - c->maj_bias) - tp[a]) * inv;
+            tmax[a] = ((float)(b[a] * c->maj_cell - c->maj_bias) - tp[a]) * inv;
             tdelta[a] = edge * -inv;
         } else {
             step[a] = 0;
@@ -519,13 +571,17 @@ static Event delta_flight(const Ctx *c, uint32_t *seed, v3 pos, v3 dir, OrcCount
     }
     float t = 0.0f;
     for (;;) {
-        if (b[0] < 0 || b[1] < 0 || b[2] < 0 || b[0] >= c->maj_gx || b[1] >= c->maj_gy || b[2] >= c->maj_gz) {
+        if (b[0] < 0 || b[1] < 0 || b[2] < 0 || b[0] >= c->maj_vx || b[1] >= c->maj_vy || b[2] >= c->maj_vz) {
             e.pos = v3_make(fmaf(dir.x, t, pos.x), fmaf(dir.y, t, pos.y), fmaf(dir.z, t, pos.z));
-            return e; /* left the grid: no collision */
+            return e; /* left the (virtual) grid: no collision */
         }
         const float t_exit = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
-        const size_t cell = ((size_t)b[2] * c->maj_gy + b[1]) * c->maj_gx + b[0];
-        const uint8_t M = c->maj[cell];
+        /* a cell outside the stored box has majorant 0 (the kernel ends a flight that LEAVES the box -- a straight line does not
+         * come back into a box, and nothing out there draws a random number -- and walks one that starts outside up to it) */
+        const int32_t sx = b[0] - c->maj_x0, sy = b[1] - c->maj_y0, sz = b[2] - c->maj_z0;
+        const int stored = sx >= 0 && sy >= 0 && sz >= 0 && sx < c->maj_gx && sy < c->maj_gy && sz < c->maj_gz;
+        const size_t cell = stored ? ((size_t)sz * c->maj_gy + sy) * c->maj_gx + sx : 0;
+        const uint8_t M = stored ? c->maj[cell] : 0;
         if (M != 0) {
             const float sigma_bar = ((float)M * (1.0f / 255.0f)) * c->density_multiplier;
             const float mean_free = 1.0f / sigma_bar; /* (the kernel keeps both in a 256-entry LDS table) */

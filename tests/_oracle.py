@@ -47,9 +47,11 @@ class OrcScene(C.Structure):
         ("maj_gx", C.c_int32),
         ("maj_gy", C.c_int32),
         ("maj_gz", C.c_int32),
-        ("maj_shift", C.c_int32),
+        ("maj_cell", C.c_int32),
         ("maj_codes", C.c_void_p),
         ("inscatter_valid", C.c_void_p),
+        ("maj_origin", C.c_int32 * 3),
+        ("maj_virtual", C.c_int32 * 3),
     ]
 
 
@@ -133,8 +135,8 @@ def lib(fast=False):
     L.orc_inscatter_texels.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32]
     L.orc_point_radiance_launch.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.POINTER(OrcCounters), C.c_int32]
-    L.orc_majorant_grid.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
-    L.orc_build_majorants.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.orc_majorant_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    L.orc_build_majorants.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.orc_generate_scatter_samples.argtypes = [C.POINTER(OrcScene), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.orc_collect_descriptors.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.orc_collect_descriptors.restype = None
@@ -246,16 +248,20 @@ class Oracle:
         s.estimator = self.estimator
         if self.estimator == 1:
             dims = np.array([nx, ny, nz], np.uint32)
-            grid = np.zeros(5, np.int32)
-            self.L.orc_majorant_grid(_ptr(dims), self.sample_step, _ptr(grid))
-            bias, gx, gy, gz, shift = (int(v) for v in grid)
+            grid = np.zeros(11, np.int32)
+            self.L.orc_majorant_grid(_ptr(self.density), _ptr(dims), self.sample_step, _ptr(grid))
+            bias, cell = int(grid[0]), int(grid[1])
+            origin = np.ascontiguousarray(grid[2:5])
+            gx, gy, gz = (int(v) for v in grid[5:8])
             self.majorant = np.empty((gz, gy, gx), np.uint8)
             self.majorant_codes = np.empty((gz, gy, gx), np.uint8)
-            self.L.orc_build_majorants(_ptr(self.density), _ptr(dims), bias, shift, gx, gy, gz, _ptr(self.majorant),
+            self.L.orc_build_majorants(_ptr(self.density), _ptr(dims), bias, cell, _ptr(origin), gx, gy, gz, _ptr(self.majorant),
                                        _ptr(self.majorant_codes))
             s.majorant = self.majorant.ctypes.data
             s.maj_codes = self.majorant_codes.ctypes.data
-            s.maj_bias, s.maj_gx, s.maj_gy, s.maj_gz, s.maj_shift = bias, gx, gy, gz, shift
+            s.maj_bias, s.maj_gx, s.maj_gy, s.maj_gz, s.maj_cell = bias, gx, gy, gz, cell
+            s.maj_origin[:] = [int(v) for v in grid[2:5]]
+            s.maj_virtual[:] = [int(v) for v in grid[8:11]]
         self.scene = s
         self.inscatter_valid = None
         if self.inscatter is None:

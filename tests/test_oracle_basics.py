@@ -398,14 +398,15 @@ def test_delta_lower_bound_codes_only_skip_lookups():
     o = O.Oracle(tex, 24, 16, mode=0, estimator=1, cloud_size_m=700.0)
     M, q = o.majorant.astype(np.int64), o.majorant_codes.astype(np.int64)
     s = o.scene
-    bias, c = s.maj_bias, 1 << s.maj_shift
+    bias, c = s.maj_bias, s.maj_cell
+    ox, oy, oz = (int(v) for v in s.maj_origin)          # virtual cell of the first stored one (round 4: the grid is cropped)
     gz, gy, gx = M.shape
     for cz in range(gz):
         for cy in range(gy):
             for cx in range(gx):
-                zs = np.clip(np.arange(c * cz - bias - 1, c * cz - bias + c + 2), 0, nz - 1)
-                ys = np.clip(np.arange(c * cy - bias - 1, c * cy - bias + c + 2), 0, ny - 1)
-                xs = np.clip(np.arange(c * cx - bias - 1, c * cx - bias + c + 2), 0, nx - 1)
+                zs = np.clip(np.arange(c * (cz + oz) - bias - 1, c * (cz + oz) - bias + c + 2), 0, nz - 1)
+                ys = np.clip(np.arange(c * (cy + oy) - bias - 1, c * (cy + oy) - bias + c + 2), 0, ny - 1)
+                xs = np.clip(np.arange(c * (cx + ox) - bias - 1, c * (cx + ox) - bias + c + 2), 0, nx - 1)
                 blk = tex[np.ix_(zs, ys, xs)]
                 assert M[cz, cy, cx] == blk.max()
                 assert 0 <= q[cz, cy, cx] <= 3 and (q[cz, cy, cx] * M[cz, cy, cx]) >> 2 <= blk.min()
@@ -538,3 +539,44 @@ def test_oracle_with_fixed_point_filter_weights_agrees_statistically():
     assert 5e-3 < dist[96] < 5e-2 and dist[96] < 0.75 * dist[24]          # noise-sized, and falling like noise (1/2 expected)
     d = np.abs(b.inscatter.astype(np.int32) - a.inscatter.astype(np.int32))
     assert d.max() <= 1 and (d != 0).mean() < 0.01
+
+
+def test_delta_grid_is_cropped_to_the_cloud_and_the_crop_changes_nothing():
+    """The DELTA twin's majorant grid (round 4): cubic cells of C texels -- any C >= 4, not only powers of two -- of which
+    only the box of cells around the non-zero texels is stored; a virtual cell outside it has majorant 0.  For a small cloud in
+    a big volume the stored box is a fraction of the virtual grid, every cell outside it really is empty, and a render is
+    bit-identical to one whose grid stores EVERY virtual cell (the crop is an exact transformation, like the kernel's ending of
+    a flight that leaves the box).  For the benchmark cloud the rule gives finer cells than the whole volume would allow."""
+    import deepestscatter_amd as ds
+    tex = np.zeros((40, 56, 48), np.uint8)
+    tex[14:26, 20:30, 30:41] = np.random.default_rng(3).integers(1, 256, (12, 10, 11)).astype(np.uint8)
+    a = O.Oracle(tex, 32, 24, estimator=1, cloud_size_m=3000.0)
+    s = a.scene
+    gz, gy, gx = a.majorant.shape
+    vx, vy, vz = (int(v) for v in s.maj_virtual)
+    ox, oy, oz = (int(v) for v in s.maj_origin)
+    assert s.maj_cell == 4 and gx * gy * gz < 0.25 * vx * vy * vz and a.majorant.max() > 0
+    # every virtual cell outside the stored box is empty: the full grid's majorants are zero there
+    full_m = np.zeros((vz, vy, vx), np.uint8)
+    full_q = np.zeros_like(full_m)
+    dims = np.array(tex.shape[::-1], np.uint32)
+    origin0 = np.zeros(3, np.int32)
+    a.L.orc_build_majorants(O._ptr(a.density), O._ptr(dims), s.maj_bias, s.maj_cell, O._ptr(origin0), vx, vy, vz, O._ptr(full_m), O._ptr(full_q))
+    inside = np.zeros_like(full_m, bool)
+    inside[oz:oz + gz, oy:oy + gy, ox:ox + gx] = True
+    assert full_m[~inside].max() == 0 and np.array_equal(full_m[inside].reshape(gz, gy, gx), a.majorant)
+    mean, m2 = a.render(4)
+    ka = a.counters.as_dict()
+    b = O.Oracle(tex, 32, 24, estimator=1, cloud_size_m=3000.0)
+    b.majorant, b.majorant_codes = full_m, full_q
+    b.scene.majorant, b.scene.maj_codes = full_m.ctypes.data, full_q.ctypes.data
+    b.scene.maj_gx, b.scene.maj_gy, b.scene.maj_gz = vx, vy, vz
+    b.scene.maj_origin[:] = [0, 0, 0]
+    mean_b, m2_b = b.render(4)
+    assert np.array_equal(mean, mean_b) and np.array_equal(m2, m2_b) and ka == b.counters.as_dict() and mean[..., 0].max() > 0
+    # the benchmark cloud (a quarter-size copy keeps the test short): finer cells than a grid over the whole volume
+    cloud = ds.make_procedural_cloud(128)
+    c = O.Oracle(cloud, 16, 16, estimator=1, inscatter="none")
+    whole = (128 + 2 * c.scene.maj_bias)
+    assert c.scene.maj_cell < 8 and c.majorant.size <= 43008 < (whole // c.scene.maj_cell) ** 3
+

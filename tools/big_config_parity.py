@@ -38,5 +38,5 @@ for est in (0, 1):
     bad += 0 if ok else 1
     print(f"estimator {('MARCH', 'DELTA')[est]}: window {win} x {spp} spp {'bit-identical' if ok else 'MISMATCH'}, "
           f"window mean radiance {float(rm[y0:y0 + 12, x0:x0 + 12, 0].mean()):.4f}, "
-          f"{'majorant cell shift %d, ' % orc.scene.maj_shift if est else ''}oracle {time.time() - t0:.1f} s", flush=True)
+          f"{'majorant cells of %d texels, ' % orc.scene.maj_cell if est else ''}oracle {time.time() - t0:.1f} s", flush=True)
 print("done:", "ok" if bad == 0 else f"{bad} mismatches")

@@ -2052,7 +2052,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
     bool drained = false;
     uint32_t c_dl = 0, c_il = 0, c_cap = 0;
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
-    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0;
+    uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_empty = 0;   // (st_empty: crossings of cells whose majorant is zero)
     uint32_t iv_dealt = 0, iv_written = 0, iv_resumed = 0, iv_suspended = 0; // path conservation (STATS kernels)
     uint32_t st_hist_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, st_hist_s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // visits by lanes taking part (bins of 8)
     uint32_t st_drained_t = 0;                                                                          // tracking visits after the wave found the job list empty
@@ -2307,6 +2307,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                         dda_cross(dda, dir);
                         if (STATS) {
                             st_skip += 1;
+                            st_empty += (M == 0u) ? 1u : 0u;
                         }
                     }
                 }
@@ -2466,9 +2467,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
         vals[i] = v;
     }
     if (STATS) {
-        uint32_t sv[7] = { st_fetch, st_zero, st_skip, iv_dealt, iv_resumed, iv_written, iv_suspended };
+        uint32_t sv[8] = { st_fetch, st_zero, st_skip, iv_dealt, iv_resumed, iv_written, iv_suspended, st_empty };
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
+        for (int i = 0; i < 8; i++) {
             uint32_t v = sv[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -2490,6 +2491,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                 atomicAdd(&ba.stats[16 + i], (unsigned long long)st_hist_t[i]);
                 atomicAdd(&ba.stats[24 + i], (unsigned long long)st_hist_s[i]);
             }
+            atomicAdd(&ba.stats[9], (unsigned long long)sv[7]);
             atomicAdd(&ba.stats[32], (unsigned long long)st_drained_t);
             atomicAdd(&ba.stats[64], (unsigned long long)sv[3]);
             atomicAdd(&ba.stats[65], (unsigned long long)sv[4]);

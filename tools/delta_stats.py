@@ -23,6 +23,8 @@ paths = k1["paths"] - k0["paths"]
 for n in ("regen_phases", "regen_lanes", "march_phases", "march_lanes", "scatter_phases", "scatter_lanes", "fetched_steps",
           "fetched_zero_cells", "skipped_steps"):
     print(f"{n:28s} {(s1[n] - s0[n]) / paths:10.3f} per sample")
+if est == 1:
+    print(f"{'crossings of empty cells':28s} {(s1['raw'][9] - s0['raw'][9]) / paths:10.3f} per sample   (of skipped_steps)")
 for n in ("density_lookups", "inscatter_lookups", "scatter_events"):
     print(f"{n:28s} {(k1[n] - k0[n]) / paths:10.3f} per sample")
 import numpy as np

@@ -70,6 +70,10 @@ VARIANTS = {
     "exp": ["-DCT_EXPERIMENTS"],
     "w8": ["-DCT_DELTA_THREADS=1024", "-DCT_DELTA_WAVES=8"],
     "nofuse": ["-DCT_DELTA_FUSE=0", "-DCT_MARCH_FUSE=0", "-DCT_DELTA_CHECK_EVERY=1"],
+    "noendmerge": ["-DCT_DELTA_END_MERGE=0"],
+    "ab1": os.environ.get("CT_AB1_FLAGS", "").split(),   # scratch variants for A/B runs of compile-time switches
+    "ab2": os.environ.get("CT_AB2_FLAGS", "").split(),
+    "ab3": os.environ.get("CT_AB3_FLAGS", "").split(),
 }
 
 

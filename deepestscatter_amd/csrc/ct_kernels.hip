@@ -1824,6 +1824,10 @@ constexpr bool DELTA_FUSE = CT_DELTA_FUSE != 0;
 #define CT_DELTA_CHECK_EVERY 2   // (5303 -> 5324 Msamples/s against 1, profiles/r04o; -DCT_DELTA_CHECK_EVERY=1: after every visit, as until round 4)
 #endif
 constexpr uint32_t DELTA_CHECK_EVERY = CT_DELTA_CHECK_EVERY;
+#ifndef CT_DELTA_END_MERGE
+#define CT_DELTA_END_MERGE 1     // (a flight that crosses out of the stored box ends in the visit of that crossing; 0: in its next visit, as until round 4)
+#endif
+constexpr bool DELTA_END_MERGE = CT_DELTA_END_MERGE != 0;
 constexpr int kDeltaThreads = CT_DELTA_THREADS;
 
 struct Dda {
@@ -1851,6 +1855,25 @@ CT_DEV uint32_t cell_index(const DevScene &sc, const Dda &d)
 {
     return __umul24((uint32_t)(d.bz - sc.mc_z0), (uint32_t)(sc.mc_gx * sc.mc_gy)) + __umul24((uint32_t)(d.by - sc.mc_y0), (uint32_t)sc.mc_gx) +
            (uint32_t)(d.bx - sc.mc_x0);
+}
+
+// The same two for a flight whose cell coordinates are kept RELATIVE to the stored box's first cell (render_delta_kernel with
+// DELTA_END_MERGE: no subtraction per visit).
+CT_DEV bool cell_in_grid_rel(const DevScene &sc, const Dda &d)
+{
+    return ((uint32_t)d.bx < (uint32_t)sc.mc_gx) & ((uint32_t)d.by < (uint32_t)sc.mc_gy) & ((uint32_t)d.bz < (uint32_t)sc.mc_gz);
+}
+CT_DEV uint32_t cell_index_rel(const DevScene &sc, const Dda &d)
+{
+    return __umul24((uint32_t)d.bz, (uint32_t)(sc.mc_gx * sc.mc_gy)) + __umul24((uint32_t)d.by, (uint32_t)sc.mc_gx) + (uint32_t)d.bx;
+}
+CT_DEV bool dda_enter_box(const DevScene &sc, Dda &d)   // absolute -> relative; is the flight's cell a stored one?
+{
+    const bool inside = cell_in_grid(sc, d);
+    d.bx -= sc.mc_x0;
+    d.by -= sc.mc_y0;
+    d.bz -= sc.mc_z0;
+    return inside;
 }
 
 CT_DEV void dda_cross(Dda &d, f3 dir);
@@ -1885,10 +1908,17 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
         TMAX = moving ? ((float)bound - TP) * inv : inf;
         TDELTA = moving ? edge * fabsf(inv) : inf;
     };
+    // (every lane of the wave moderate: no component is zero, so the test for a resting axis -- a divergent region per axis in
+    // the compiled code -- is left out; the values are the same.  5525 -> 5603 Msamples/s, profiles/r04aa)
+    auto axis_moving = [&](int32_t B, float TP, float V, float inv, float &TMAX, float &TDELTA) {
+        const int32_t bound = (int32_t)__umul24((uint32_t)(B + (V > 0.0f ? 1 : 0)), (uint32_t)sc.mc_cell) - sc.brick_bias;
+        TMAX = ((float)bound - TP) * inv;
+        TDELTA = edge * fabsf(inv);
+    };
     if (__builtin_amdgcn_ballot_w64(!moderate) == 0ull) {
-        axis(d.bx, tpx, vx, rcp_moderate(vx), d.tmax.x, d.tdelta.x);
-        axis(d.by, tpy, vy, rcp_moderate(vy), d.tmax.y, d.tdelta.y);
-        axis(d.bz, tpz, vz, rcp_moderate(vz), d.tmax.z, d.tdelta.z);
+        axis_moving(d.bx, tpx, vx, rcp_moderate(vx), d.tmax.x, d.tdelta.x);
+        axis_moving(d.by, tpy, vy, rcp_moderate(vy), d.tmax.y, d.tdelta.y);
+        axis_moving(d.bz, tpz, vz, rcp_moderate(vz), d.tmax.z, d.tdelta.z);
     } else {
         axis(d.bx, tpx, vx, rcp_(vx), d.tmax.x, d.tdelta.x);
         axis(d.by, tpy, vy, rcp_(vy), d.tmax.y, d.tdelta.y);
@@ -1908,6 +1938,8 @@ CT_DEV void dda_cross(Dda &d, f3 dir)
 {
     const float t_exit = fminf(fminf(d.tmax.x, d.tmax.y), d.tmax.z);
     d.t = t_exit;
+    // (three exclusive divergent regions; as selects -- three lane masks alive at once in a kernel that already spills scalar
+    // registers -- the DELTA kernel lost 5 %: 5628 -> 5325 Msamples/s, profiles/r04aa)
     if (d.tmax.x <= d.tmax.y && d.tmax.x <= d.tmax.z) {
         d.bx += (dir.x > 0.0f) ? 1 : -1;
         d.tmax.x += d.tdelta.x;
@@ -1945,7 +1977,7 @@ __global__ __launch_bounds__(256) void primary_advance_delta_kernel(DevScene sc,
     advance[4 * p] = make_float4(d.org.x, d.org.y, d.org.z, d.t);
     advance[4 * p + 1] = make_float4(d.tmax.x, d.tmax.y, d.tmax.z, __int_as_float(d.bx));
     advance[4 * p + 2] = make_float4(d.tdelta.x, d.tdelta.y, d.tdelta.z, __int_as_float(d.by));
-    advance[4 * p + 3] = make_float4(__int_as_float(d.bz), 0.f, 0.f, 0.f);
+    advance[4 * p + 3] = make_float4(__int_as_float(d.bz), 0.f, 0.f, 0.f);   // (cell coordinates of the virtual grid; the walk may have left the stored box)
 }
 
 // Majorant of every STORED cell of the DELTA grid: the max of the texels [lo-1, lo+C+1]^3 (clamped), and the 2-bit code
@@ -2194,7 +2226,18 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                             } else {
                                 dda_begin(sc, dda, pos, dir);
                             }
-                            state = ST_MARCH;
+                            if (DELTA_END_MERGE && !dda_enter_box(sc, dda)) {
+                                // the flight never meets the stored box: what its first visit would have written
+                                ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
+                                if (STATS) {
+                                    iv_written += 1;
+                                }
+                                if (ba.cost) {
+                                    ba.cost[out_idx - ba.out_offset] = make_uint2(depth, depth);
+                                }
+                            } else {
+                                state = ST_MARCH;
+                            }
                         } else {
 #ifdef CT_DEBUG_BOUNDS
                             if (age == 0u && ba.frame_stride && out_idx - ba.out_offset >= ba.S * ba.frame_stride) {   // (a resumed path writes to an earlier batch's region)
@@ -2254,7 +2297,11 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                 rad = add3(rad, in_scattering_finish(sc, nee, pos));
                 if (go) {
                     dda_begin(sc, dda, pos, dir);
-                    state = ST_MARCH;
+                    if (DELTA_END_MERGE && !dda_enter_box(sc, dda)) {
+                        finished = true;   // (the new flight never meets the stored box)
+                    } else {
+                        state = ST_MARCH;
+                    }
                 } else {
                     finished = true;
                 }
@@ -2286,12 +2333,15 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                 // one step of the flight: cross into the next cell, or draw a tentative collision in this one
                 bool ended = false, collide = false;
                 float sigma_bar = 0.0f, sigma_low = 0.0f;
-                if (!cell_in_grid(sc, dda)) {
+                // (DELTA_END_MERGE: a marching lane's cell is always a stored one -- the crossing that leaves the box ends the flight
+                // in its own visit, and a flight that begins outside never starts marching -- so the visit begins with the look-up)
+                if (!DELTA_END_MERGE && !cell_in_grid(sc, dda)) {
                     ended = true; // left the grid without a collision
                 } else {
-                    const uint32_t ci = cell_index(sc, dda);
+                    const uint32_t ci = DELTA_END_MERGE ? cell_index_rel(sc, dda) : cell_index(sc, dda);
                     const uint32_t M = lds_maj[ci];
                     if (M != 0u) {
+                        // (requesting this byte WITH the majorant, before it is known to be non-zero, measured: no gain, profiles/r04aa)
                         const uint32_t q = ((uint32_t)lds_codes[ci >> 2] >> ((ci & 3u) * 2u)) & 3u;
                         sigma_low = sigma_table[(q * M) >> 2].x;
                         const float2 sb = sigma_table[M];
@@ -2305,6 +2355,9 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                     }
                     if (!collide) {
                         dda_cross(dda, dir);
+                        if (DELTA_END_MERGE) {
+                            ended = !cell_in_grid_rel(sc, dda);
+                        }
                         if (STATS) {
                             st_skip += 1;
                             st_empty += (M == 0u) ? 1u : 0u;

@@ -1927,6 +1927,11 @@ CT_DEV void dda_begin(const DevScene &sc, Dda &d, f3 pos, f3 dir)
     // A flight that starts OUTSIDE the stored box (a primary ray that enters the volume beside the cloud; a scatter position that
     // rounds into the neighbour of a cell on the box's face) crosses the empty virtual cells up to it, with the crossings' own
     // arithmetic -- the oracle's flight steps through the same cells one by one -- or leaves the virtual grid without meeting it.
+    // (A scatter position lies in the cloud, a pre-walked primary ray does not come here: a wave rarely holds such a lane, and asks
+    // once -- the loop's own header, two box tests per lane, is not run otherwise: +0.3 %, profiles/r04aa.)
+    if (__builtin_amdgcn_ballot_w64(!cell_in_grid(sc, d)) == 0ull) {
+        return;
+    }
     while (cell_in_virtual_grid(sc, d) && !cell_in_grid(sc, d)) {
         dda_cross(d, dir);
     }

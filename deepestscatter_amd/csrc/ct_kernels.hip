@@ -856,6 +856,12 @@ enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_BOUNCE = 2 };
 // ballots, the job and drain tests, the queue-empty hint) run once per pair of phases.  Round 4, 512^3 / 1024^2: 3297 -> 3349
 // Msamples/s (+1.6 %; DELTA, where the scheduler is a larger share: 5120 -> 5273, +3.0 %; profiles/r04i).  Schedule only.
 // -DCT_MARCH_FUSE=0 / -DCT_DELTA_FUSE=0 (build --variant nofuse): separate iterations, as until round 3.
+#ifndef CT_MARCH_FLAT_ZERO
+#define CT_MARCH_FLAT_ZERO 1   // (1: an all-zero footprint goes through the density evaluation like the others)
+#endif
+#ifndef CT_MARCH_FLAT_EXIT
+#define CT_MARCH_FLAT_EXIT 1
+#endif
 #ifndef CT_MARCH_FUSE
 #define CT_MARCH_FUSE 1
 #endif
@@ -1521,7 +1527,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     st_zero_d1 += ((cell.x | cell.y) == 0u && dfree == 1u) ? 1u : 0u;
                 }
                 bool collided = false;
-                if ((cell.x | cell.y) != 0u) {
+                if (CT_MARCH_FLAT_ZERO || (cell.x | cell.y) != 0u) {
                     // all-zero footprints give density 0, exp(-0) = 1, T unchanged: nothing to evaluate
                     const float density = filter_at(sc, cell, pos) * sc.density_multiplier;
                     const float extinction = density * sc.sample_step;
@@ -1534,10 +1540,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 }
                 // isInBox(pos), the loop condition of cloud.cuh:87.  In an "interior" brick it is
                 // known to hold (see DevScene), so the six comparisons are skipped.
+#if CT_MARCH_FLAT_EXIT
+                state = collided ? ST_BOUNCE : state;
+                dfree = collided ? (meta & 0x80u) : dfree;
+                if (!collided & ((meta & 0x80u) == 0u) & !in_box_flat(sc, pos)) {
+#else
                 if (collided) {
                     state = ST_BOUNCE;
                     dfree = meta & 0x80u;
                 } else if ((meta & 0x80u) == 0u && !in_box(sc, pos)) {
+#endif
                     ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
                     if (STATS) {
                         iv_written += 1;
@@ -1824,6 +1836,9 @@ constexpr bool DELTA_FUSE = CT_DELTA_FUSE != 0;
 #define CT_DELTA_CHECK_EVERY 2   // (5303 -> 5324 Msamples/s against 1, profiles/r04o; -DCT_DELTA_CHECK_EVERY=1: after every visit, as until round 4)
 #endif
 constexpr uint32_t DELTA_CHECK_EVERY = CT_DELTA_CHECK_EVERY;
+#ifndef CT_DELTA_FLAT_EMPTY
+#define CT_DELTA_FLAT_EMPTY 1
+#endif
 #ifndef CT_DELTA_END_MERGE
 #define CT_DELTA_END_MERGE 1     // (a flight that crosses out of the stored box ends in the visit of that crossing; 0: in its next visit, as until round 4)
 #endif
@@ -2345,6 +2360,24 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                 } else {
                     const uint32_t ci = DELTA_END_MERGE ? cell_index_rel(sc, dda) : cell_index(sc, dda);
                     const uint32_t M = lds_maj[ci];
+#if CT_DELTA_FLAT_EMPTY
+                    {
+                        // (an empty cell -- one visit in twelve -- goes through the same instructions with the table's entry 0 and keeps
+                        // its seed and its t: no divergent region around the sampling)
+                        const uint32_t q = ((uint32_t)lds_codes[ci >> 2] >> ((ci & 3u) * 2u)) & 3u;
+                        sigma_low = sigma_table[(q * M) >> 2].x;
+                        const float2 sb = sigma_table[M];
+                        sigma_bar = sb.x;
+                        uint32_t drawn = seed;
+                        const float u = u24_to_float(lcg24(drawn));
+                        const float dt = -logf_above_one(1.0f - u) * sb.y;
+                        const float t_exit = fminf(fminf(dda.tmax.x, dda.tmax.y), dda.tmax.z);
+                        const float t_next = dda.t + dt;
+                        collide = (M != 0u) & (t_next < t_exit);
+                        seed = (M != 0u) ? drawn : seed;
+                        dda.t = collide ? t_next : dda.t;
+                    }
+#else
                     if (M != 0u) {
                         // (requesting this byte WITH the majorant, before it is known to be non-zero, measured: no gain, profiles/r04aa)
                         const uint32_t q = ((uint32_t)lds_codes[ci >> 2] >> ((ci & 3u) * 2u)) & 3u;
@@ -2358,6 +2391,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                         collide = t_next < t_exit;
                         dda.t = collide ? t_next : dda.t;
                     }
+#endif
                     if (!collide) {
                         dda_cross(dda, dir);
                         if (DELTA_END_MERGE) {

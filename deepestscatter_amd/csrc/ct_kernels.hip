@@ -1474,10 +1474,84 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             // once the queue is empty nothing is left to amortise: what remains of the launch is the
             // latency of its longest paths, so a collided lane no longer waits for a burst to end
             uint32_t burst = drained ? sc.tail_burst : sc.march_burst;
+            for (;;) {
+            if (state == ST_MARCH) {
+                // Free-space skip: every brick within Chebyshev distance dfree-1 of the one `pos` is
+                // in is free, so the next n steps can neither collide (all 8 texels are 0, T *= 1)
+                // nor leave the box; only the position updates have to be replayed (same float adds
+                // in the same order -> bit-identical path).  They still count as density lookups:
+                // the counter is the algorithm's lookup count, not the loads this kernel issued.
+                if (dfree != 0u) {
+                    const int n = skip_steps(dfree, inv_maxd);
+                    replay_steps(pos, stepv, n);
+                    c_dl += (uint32_t)n;
+                    if (STATS) {
+                        st_skip += (uint32_t)n;
+                        // wave-level iterations of the replay loop = the largest n of the wave
+                        int wmax = n;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) {
+                            wmax = max(wmax, __shfl_xor(wmax, off));
+                        }
+                        st_skip_iters += (lane_rank(__builtin_amdgcn_ballot_w64(true)) == 0u) ? (uint32_t)wmax : 0u;
+                    }
+                }
+                pos = add3(pos, stepv);
+                uint32_t meta;
+                const uint2 cell = fetch_cell_m<SPARSE>(sc, pos, meta);
+                dfree = meta & 0x7fu;
+                c_dl += 1;
+                work += 1u;
+                if (STATS) {
+                    st_fetch += 1;
+                    // (round-3 question: would a brick cache in LDS find anything?  The 128-B line of this footprint against
+                    // the lane's previous one, and against the lines the wave's other lanes fetch in this same instruction.)
+                    {
+                        const float fx = fmaf(pos.x, sc.sx, -0.5f), fy = fmaf(pos.y, sc.sy, -0.5f), fz = fmaf(pos.z, sc.sz, -0.5f);
+                        const uint32_t lx = (uint32_t)(floor_to_int(fx) + sc.m_bias_x), ly = (uint32_t)(floor_to_int(fy) + sc.brick_bias),
+                                       lz = (uint32_t)(floor_to_int(fz) + sc.brick_bias);
+                        const uint32_t line = __umul24(lz >> 2, (uint32_t)sc.m_gxy) + __umul24(ly >> 2, (uint32_t)sc.m_gx) + (__umul24(lx, 43691u) >> 17);
+                        st_same_line += (line == st_prev_line) ? 1u : 0u;
+                        st_prev_line = line;
+                        if (ba.touched_density && !SPARSE) {   // ct_debug_track_lines: the distinct 128-B lines a launch reads
+                            atomicOr(&ba.touched_density[line >> 5], 1u << (line & 31u));
+                        }
+                        const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+                        bool dup = false;
+                        for (uint32_t i = 0; i < 64u; i++) {
+                            const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)line, (int)i);
+                            dup = dup || (((act >> i) & 1ull) != 0ull && i < lane && other == line);
+                        }
+                        st_dup_line += dup ? 1u : 0u;
+                    }
+                    st_zero += ((cell.x | cell.y) == 0u) ? 1u : 0u;
+                    st_zero_d0 += ((cell.x | cell.y) == 0u && dfree == 0u) ? 1u : 0u;
+                    st_zero_d1 += ((cell.x | cell.y) == 0u && dfree == 1u) ? 1u : 0u;
+                }
+                bool collided = false;
+                if (CT_MARCH_FLAT_ZERO || (cell.x | cell.y) != 0u) {
+                    // all-zero footprints give density 0, exp(-0) = 1, T unchanged: nothing to evaluate
+                    const float density = filter_at(sc, cell, pos) * sc.density_multiplier;
+                    const float extinction = density * sc.sample_step;
+                    T *= expf_inrange(-extinction);
+                    if (xi > T) {
+                        // collision: scatterPos and its box test are evaluated by the scatter phase
+                        collided = true;
+                        inv_maxd = density;
+                    }
+                }
+                // isInBox(pos), the loop condition of cloud.cuh:87.  In an "interior" brick it is
+                // known to hold (see DevScene), so the six comparisons are skipped.
+#if CT_MARCH_FLAT_EXIT
+                state = collided ? ST_BOUNCE : state;
+                dfree = collided ? (meta & 0x80u) : dfree;
+                if (!collided & ((meta & 0x80u) == 0u) & !in_box_flat(sc, pos)) {
+#else
                 if (collided) {
                     state = ST_BOUNCE;
                     dfree = meta & 0x80u;
                 } else if ((meta & 0x80u) == 0u && !in_box(sc, pos)) {
+#endif
                     ba.frames[out_idx] = make_float4(rad.x, rad.y, rad.z, 1.f);
                     if (STATS) {
                         iv_written += 1;

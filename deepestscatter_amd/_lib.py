@@ -24,7 +24,7 @@ EXPORTS = [
     "ct_create", "ct_destroy", "ct_last_error", "ct_set_stream", "ct_set_camera", "ct_render_subframe",
     "ct_accumulate", "ct_render_accumulate", "ct_render_accumulate_async", "ct_synchronize", "ct_copy_to_device_async", "ct_point_radiance_launch", "ct_generate_scatter_samples", "ct_collect_descriptors", "ct_reset", "ct_tonemap", "ct_tonemap_async", "ct_set_render_ahead", "ct_rendered_subframes", "ct_set_stop_when_converged", "ct_converged_at", "ct_is_converged", "ct_tonemap_buffer", "ct_is_converged_buffers", "ct_download", "ct_upload",
     "ct_buffer_bytes", "ct_copy_to_device", "ct_device_ptr", "ct_subframes", "ct_set_subframes", "ct_counters", "ct_kernel_time",
-    "ct_debug_cdf_inversion", "ct_debug_math_selftest", "ct_debug_fetch_probe", "ct_debug_fetch_probe_ws", "ct_debug_track_lines", "ct_debug_touched_lines", "ct_debug_stats", "ct_debug_stats_ex", "ct_debug_suspended", "ct_debug_timeline", "ct_debug_invariants", "ct_debug_memory", "ct_fetch_counters", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_load_vdb", "ct_generate_mipmaps",
+    "ct_debug_cdf_inversion", "ct_debug_math_selftest", "ct_debug_fetch_probe", "ct_debug_fetch_probe_ws", "ct_debug_track_lines", "ct_debug_touched_lines", "ct_debug_stats", "ct_debug_stats_ex", "ct_debug_suspended", "ct_debug_timeline", "ct_debug_invariants", "ct_debug_memory", "ct_debug_delta_grid", "ct_fetch_counters", "ct_calculate_camera_variables", "ct_quantize_volume", "ct_load_vdb", "ct_generate_mipmaps",
     "ct_tile_owner", "ct_make_procedural_cloud",
     "ct_group_create", "ct_group_destroy", "ct_group_last_error", "ct_group_size", "ct_group_handle", "ct_group_set_camera",
     "ct_group_render_accumulate", "ct_group_reset", "ct_group_merge", "ct_group_download", "ct_group_tonemap",
@@ -142,6 +142,7 @@ def load():
         "ct_debug_stats_ex": (i32, [vp, vp, C.c_uint32]),
         "ct_debug_invariants": (i32, [vp, vp]),
         "ct_debug_memory": (i32, [vp, vp]),
+        "ct_debug_delta_grid": (i32, [vp, vp]),
         "ct_fetch_counters": (i32, [vp, C.POINTER(CtFetchCounters)]),
         "ct_debug_fetch_probe": (i32, [i32, u32, u32, C.POINTER(C.c_uint64)]),
         "ct_debug_fetch_probe_ws": (i32, [i32, u32, C.c_uint64, u32, C.POINTER(C.c_uint64)]),

@@ -428,6 +428,13 @@ class CloudTracer:
                  "row_table", "coarse_clearance"]
         return {n: int(v) for n, v in zip(names, out)}
 
+    def delta_grid(self) -> dict:
+        """The DELTA estimator's majorant grid and kernel variant (ct_debug_delta_grid)."""
+        out = np.zeros(8, np.uint32)
+        check(self.L.ct_debug_delta_grid(self.h, _p(out)), self.h)
+        return {"cell": int(out[0]), "stored": tuple(int(v) for v in out[1:4]), "origin": tuple(int(v) for v in out[4:7]),
+                "nee": int(out[7] & 0xff), "interior": bool(out[7] & 0x100)}
+
     def kernel_time(self):
         """-> (estimator kernel ms, accumulate kernel ms, estimator launches) since create/reset."""
         a, b, n = C.c_double(0), C.c_double(0), C.c_uint64(0)

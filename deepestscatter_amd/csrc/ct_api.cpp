@@ -34,7 +34,7 @@ struct Knob {
     const char *get() const { return is_set ? text.c_str() : nullptr; }
     explicit operator bool() const { return is_set; }
 };
-#define CT_KNOBS(X) X(BURST_IDLE) X(BURST_MARCH_MIN) X(BURST_SCATTER) X(CHUNK_INTERLEAVE) X(CHUNK_MORTON) X(CONTINUATION) X(DEBUG_INVARIANTS) X(DELTA_NEE) X(EXCHANGE) X(HAND_ON_JOBS) X(HINT_PERIOD) X(JOB_MAX) X(JOB_WORK) X(MARCH_BURST) X(MAX_AGE) X(NEE_CACHE) X(NO_ADVANCE) X(POINT_BLOCKS_PER_CU) X(POINT_ORDER) X(REGEN_MIN) X(RENDER_AHEAD) X(SCATTER_MIN) X(SCATTER_RATIO) X(SCRATCH_GIB) X(SCRATCH_MIB) X(SERPENTINE) X(SHARED_DEPTH) X(SPARSE) X(STATS) X(TAIL_BURST) X(TILE_ORDER) X(TIMELINE) X(TRACE) X(TUNE_SUBFRAMES) X(XCD_QUEUES) X(XCD_QUEUES_UNTUNED) X(XCD_REGIONS) X(BLOCKS_PER_CU)
+#define CT_KNOBS(X) X(BURST_IDLE) X(BURST_MARCH_MIN) X(BURST_SCATTER) X(CHUNK_INTERLEAVE) X(CHUNK_MORTON) X(CONTINUATION) X(DEBUG_INVARIANTS) X(DELTA_INTERIOR) X(DELTA_NEE) X(EXCHANGE) X(HAND_ON_JOBS) X(HINT_PERIOD) X(JOB_MAX) X(JOB_WORK) X(MARCH_BURST) X(MAX_AGE) X(NEE_CACHE) X(NO_ADVANCE) X(POINT_BLOCKS_PER_CU) X(POINT_ORDER) X(REGEN_MIN) X(RENDER_AHEAD) X(SCATTER_MIN) X(SCATTER_RATIO) X(SCRATCH_GIB) X(SCRATCH_MIB) X(SERPENTINE) X(SHARED_DEPTH) X(SPARSE) X(STATS) X(TAIL_BURST) X(TILE_ORDER) X(TIMELINE) X(TRACE) X(TUNE_SUBFRAMES) X(XCD_QUEUES) X(XCD_QUEUES_UNTUNED) X(XCD_REGIONS) X(BLOCKS_PER_CU)
 struct CtTuning {
 #define X(name) Knob name;
     CT_KNOBS(X)
@@ -935,6 +935,20 @@ static int create_impl(const CtScene *s, CtHandle h)
         d.mc_vx = virt[0];
         d.mc_vy = virt[1];
         d.mc_vz = virt[2];
+        // (a real collision has a non-zero texel in its footprint, i.e. its texel coordinate is within one texel of the non-zero
+        // texels' bounding box: two texels of margin put it inside the box whatever the rounding; CT_DELTA_INTERIOR=0: always test)
+        d.delta_interior = 1u;
+        // (and a tentative collision lies in a stored cell -- to a hundredth of a texel: the error of the crossings' sums -- so
+        // when the stored box, grown by one texel, is inside the brick grid its texel index needs no clamp)
+        const int32_t bg[3] = { d.brick_gx, d.brick_gy, d.brick_gz };
+        for (int a = 0; a < 3; a++) {
+            if (lo[a] < 2 || hi[a] > n[a] - 3 || C * origin[a] < 1 || C * (origin[a] + stored[a]) > 4 * bg[a] - 1) {
+                d.delta_interior = 0u;
+            }
+        }
+        if (const char *e = h->tune.DELTA_INTERIOR.get()) {
+            d.delta_interior = (atoi(e) != 0 && d.delta_interior) ? 1u : 0u;
+        }
     }
     // which of the volume's six boundary layers are empty (launch_inscatter: a march that leaves through one of those is over)
     uint32_t zero_faces = 0;
@@ -3273,6 +3287,25 @@ extern "C" int ct_debug_memory(CtHandle h, uint64_t out[8])
     out[5] = h->dev.m_rows ? 1 : (h->vmm.va ? 2 : 0);   // 1 row extents, 2 dense addressing with sparse backing (out[4] = the memory behind it)
     out[6] = h->dev.m_rows ? (size_t)h->dev.brick_gy * h->dev.brick_gz * sizeof(uint2) : 0;
     out[7] = h->dev.m_rows ? (size_t)h->dev.m_cgxy * (size_t)((4 * h->dev.brick_gz + 7) >> h->dev.m_cshift) : 0;
+    return CT_OK;
+}
+
+extern "C" int ct_debug_delta_grid(CtHandle h, uint32_t out[8])
+{
+    NEED(h);
+    if (!out) {
+        return fail(h, CT_E_INVAL, "out is NULL");
+    }
+    const DevScene &d = h->dev;
+    const bool delta = d.maj_cells != nullptr;
+    out[0] = delta ? (uint32_t)d.mc_cell : 0u;
+    out[1] = delta ? (uint32_t)d.mc_gx : 0u;
+    out[2] = delta ? (uint32_t)d.mc_gy : 0u;
+    out[3] = delta ? (uint32_t)d.mc_gz : 0u;
+    out[4] = delta ? (uint32_t)d.mc_x0 : 0u;
+    out[5] = delta ? (uint32_t)d.mc_y0 : 0u;
+    out[6] = delta ? (uint32_t)d.mc_z0 : 0u;
+    out[7] = delta ? (d.delta_nee | (d.delta_interior ? 0x100u : 0u)) : 0u;
     return CT_OK;
 }
 

@@ -139,6 +139,10 @@ struct DevScene {
     int32_t t_bias;             // added to a texel index to make it non-negative (multiple of 3)
     int32_t t_gx, t_gy, t_gz;   // bricks per axis
     uint32_t delta_nee;         // render_delta_kernel<.., NEE>: 0, 1 or 2 (2 only with tbricks)
+    uint32_t delta_interior;    // 1: every non-zero texel lies at least two texels inside the volume's faces, so a REAL collision of the
+                                // DELTA flight -- a position with a non-zero footprint -- is inside the box and isInBox is not evaluated;
+                                // AND every stored majorant cell lies a texel or more inside the brick grid, so the texel index of a
+                                // tentative collision needs no clamp (render_delta_kernel<.., INTERIOR = true>)
     const uint8_t *maj_cells;
     const uint8_t *maj_codes;   // per cell q = min(3, 4*min/max) of its texels: texel value (q*M) >> 2 bounds the cell from below
     // (round 4) A VIRTUAL grid of mc_vx x mc_vy x mc_vz cubic cells of mc_cell texels (any size >= 4) covers [-brick_bias, n + brick_bias);
@@ -369,6 +373,24 @@ CT_DEV size_t apron_offset_in_grid(const DevScene &sc, f3 p)
     const uint32_t uz = (uint32_t)(min(max(floor_to_int(z), lo), 4 * sc.brick_gz - 1 + lo) + sc.brick_bias);
     const uint32_t brick = __umul24(uz >> 2, (uint32_t)sc.brick_gxy) + __umul24(uy >> 2, (uint32_t)sc.brick_gx) + (ux >> 2);
     const uint32_t local = __umul24(uz & 3u, 25u) + __umul24(uy & 3u, 5u) + (ux & 3u);
+    return ((size_t)brick << 7) | local;
+}
+// The same without the clamp, for scenes whose stored majorant cells all lie a texel or more inside the brick grid
+// (DevScene::delta_interior): there the clamp never changes an index.
+CT_DEV size_t apron_offset_unclamped(const DevScene &sc, f3 p)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    const uint32_t ux = (uint32_t)(floor_to_int(x) + sc.brick_bias);
+    const uint32_t uy = (uint32_t)(floor_to_int(y) + sc.brick_bias);
+    const uint32_t uz = (uint32_t)(floor_to_int(z) + sc.brick_bias);
+    const uint32_t brick = __umul24(uz >> 2, (uint32_t)sc.brick_gxy) + __umul24(uy >> 2, (uint32_t)sc.brick_gx) + (ux >> 2);
+    const uint32_t local = __umul24(uz & 3u, 25u) + __umul24(uy & 3u, 5u) + (ux & 3u);
+#ifdef CT_DEBUG_BOUNDS
+    if ((ux >> 2) >= (uint32_t)sc.brick_gx || (uy >> 2) >= (uint32_t)sc.brick_gy || (uz >> 2) >= (uint32_t)sc.brick_gz) {
+        printf("CT_DEBUG_BOUNDS unclamped footprint texel (%u,%u,%u) outside the brick grid\n", ux, uy, uz);
+        return 0;
+    }
+#endif
     return ((size_t)brick << 7) | local;
 }
 // The two 8-byte loads of a footprint, not yet combined (a load that is consumed later leaves the wave free meanwhile).

@@ -2062,7 +2062,9 @@ hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primar
 //   2  twin bricks (DevScene::tbricks): both footprints in one 128-byte line, the shadow half requested like in 1 -- an L1/L2
 //      hit on the line the density lookup has just brought, or that line's one fill when the lower bound made the lookup
 //      unnecessary.
-template <int MODE, bool STATS, int NEE>
+// INTERIOR: DevScene::delta_interior as a compile-time fact (the box test of a real collision and its three scene constants are
+// not in the kernel at all; as a run-time test it cost 3.4 %: the kernel spills scalar registers).  Instantiated for NEE = 1 only.
+template <int MODE, bool STATS, int NEE, bool INTERIOR = false>
 __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(CT_DELTA_WAVES))) void render_delta_kernel(DevScene sc, BatchArgs ba)
 {
     // 24 KiB of Mie tables + 40 KiB of majorants + 10 KiB of lower-bound codes + 2 KiB per block of 768 threads:
@@ -2416,7 +2418,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                     // apron bricks, or the density half of the twin line; inside the box the clamp to the grid changes nothing)
                     size_t off = 0;
                     if (NEE == 1) {
-                        off = apron_offset_in_grid(sc, p);
+                        off = INTERIOR ? apron_offset_unclamped(sc, p) : apron_offset_in_grid(sc, p);
                     } else if (NEE == 2) {
                         off = twin_offset_in_grid(sc, p);
                     }
@@ -2443,7 +2445,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                     }
                     // (one divergent region instead of two nested ones: the box test runs under the collision's mask -- the same
                     // wave instructions as under the real collisions' -- and the position is a select)
-                    const bool bounce = real & in_box_flat(sc, p);
+                    const bool bounce = INTERIOR ? real : (real & in_box_flat(sc, p));
                     ended = ended | (real & !bounce);
                     pos = mk3(real ? p.x : pos.x, real ? p.y : pos.y, real ? p.z : pos.z);
                     if (bounce) {
@@ -2609,6 +2611,14 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
 template <bool STATS, int NEE>
 static void launch_render_delta_mode(const DevScene &sc, const BatchArgs &ba, dim3 grid, dim3 block, hipStream_t stream)
 {
+    if (NEE == 1 && !STATS && sc.delta_interior != 0u) {
+        switch (sc.mode) {
+        case 0: hipLaunchKernelGGL((render_delta_kernel<0, false, 1, true>), grid, block, 0, stream, sc, ba); break;
+        case 1: hipLaunchKernelGGL((render_delta_kernel<1, false, 1, true>), grid, block, 0, stream, sc, ba); break;
+        default: hipLaunchKernelGGL((render_delta_kernel<2, false, 1, true>), grid, block, 0, stream, sc, ba); break;
+        }
+        return;
+    }
     switch (sc.mode) {
     case 0: hipLaunchKernelGGL((render_delta_kernel<0, STATS, NEE>), grid, block, 0, stream, sc, ba); break;
     case 1: hipLaunchKernelGGL((render_delta_kernel<1, STATS, NEE>), grid, block, 0, stream, sc, ba); break;

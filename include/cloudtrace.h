@@ -405,6 +405,13 @@ CT_API int ct_debug_invariants(CtHandle h, uint64_t out[8]);
  * (CT_FLAG_VMM_BRICKS or CT_SPARSE=2); out[3] is then the size of the address range and out[4] the memory behind it. */
 CT_API int ct_debug_memory(CtHandle h, uint64_t out[8]);
 
+/* The DELTA estimator's majorant grid and kernel variant (zeros for a MARCH handle): out[0] cell edge in texels, out[1..3] stored
+ * cells per axis, out[4..6] the stored box's first cell in the virtual grid, out[7] = NEE variant (0, 1, 2) | 0x100 when every
+ * non-zero texel lies two texels or more inside the volume's faces and the stored cells a texel or more inside the brick grid
+ * (then a real collision is inside the box and a tentative one inside the grid by construction, and the kernel instantiated
+ * without that test and that clamp runs; CT_DELTA_INTERIOR=0 keeps both). */
+CT_API int ct_debug_delta_grid(CtHandle h, uint32_t out[8]);
+
 /* PMC calibration probe (no handle): allocates 2^log2_lines 128-byte lines on `device`, and has one
  * thread per line issue the estimator's access pattern (two unaligned 8-byte loads at byte 13 and
  * byte 38 of a pseudo-randomly chosen, never repeated line).  Under rocprofv3 --pmc FETCH_SIZE this

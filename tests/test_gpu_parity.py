@@ -981,6 +981,8 @@ def test_scheduler_knobs_never_change_a_result(monkeypatch, estimator):
         # the DELTA kernel's fetch layouts (round 4): separate bricks / shadow footprint requested at the collision / twin bricks
         {"CT_DELTA_NEE": "0"}, {"CT_DELTA_NEE": "1"}, {"CT_DELTA_NEE": "2"}, {"CT_DELTA_NEE": "2", "CT_CONTINUATION": "0"},
         {"CT_DELTA_NEE": "2", "CT_XCD_QUEUES": "1", "CT_NO_ADVANCE": "1"},
+        # the DELTA kernel with the box test of a real collision (this sphere lies inside the volume: the default runs without it)
+        {"CT_DELTA_INTERIOR": "0"}, {"CT_DELTA_INTERIOR": "0", "CT_CONTINUATION": "0"},
     ]
     for env in settings:
         for k, v in env.items():
@@ -1021,6 +1023,53 @@ def test_delta_fetch_layouts_against_the_oracle(nee, monkeypatch):
         iv = tr.debug_invariants()
         assert iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
         tr.close()
+
+
+def test_delta_kernel_without_the_box_test_where_the_cloud_lies_inside_the_volume(monkeypatch):
+    """DevScene::delta_interior: when every non-zero texel lies two texels or more inside the volume's faces a REAL collision --
+    a position with a non-zero footprint -- is inside the box, and render_delta_kernel<.., INTERIOR = true> (no isInBox after
+    a real collision) runs.  The flag is set exactly at that margin; with it the results equal the oracle twin's (which always
+    tests) bit for bit on a volume that is dense right up to the margin, seen from outside and from inside, in all three
+    radiance programs; CT_DELTA_INTERIOR=0 runs the kernel with the test and gives the same."""
+    monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    rng = np.random.default_rng(23)
+
+    def slab(n, lo, hi):
+        t = np.zeros((n, n, n), np.uint8)
+        t[lo:hi + 1, lo:hi + 1, lo:hi + 1] = rng.integers(1, 256, (hi - lo + 1,) * 3).astype(np.uint8)
+        return t
+
+    for tex, want in ((slab(28, 6, 21), True), (slab(28, 1, 21), False), (slab(28, 6, 26), False), (rng.integers(0, 256, (14, 19, 26)).astype(np.uint8), False),
+                      (sphere_volume(44, radius=0.38, seed=41), True)):
+        tr = ds.CloudTracer(tex, width=16, height=16, estimator=1)
+        assert tr.delta_grid()["interior"] is want and tr.delta_grid()["nee"] == 1
+        tr.close()
+    for tex, mode, eye in [(slab(28, 6, 21), m, e) for m in (0, 1, 2) for e in ((0.3, 0.25, 3.0), (0.05, 0.02, 0.1))] + \
+                          [(slab(20, 2, 17), 0, (0.3, 0.25, 3.0)), (slab(24, 3, 20), 0, (-2.0, 0.4, 0.3))]:   # (at and near the margin: whichever kernel runs)
+        kw = dict(mode=mode, cloud_size_m=600.0, max_depth=200, estimator=1)
+        outs = []
+        for knob in (None, "0"):
+            if knob is not None:
+                monkeypatch.setenv("CT_DELTA_INTERIOR", knob)
+            tr, orc = make_pair(tex, 40, 30, **kw)
+            assert tr.delta_grid()["interior"] is (knob is None) or tex.shape[0] != 28
+            assert knob is None or not tr.delta_grid()["interior"]
+            U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, 40 / 30)
+            tr.set_camera(eye, U, V, W)
+            orc.set_camera(eye, U, V, W)
+            tr.render_accumulate_async(1, 4)
+            tr.render_accumulate(5, 3)
+            tr.render_accumulate_async(8, 5)
+            mean, m2 = orc.render(12)
+            outs.append((tr.mean(), tr.m2(), tr.counters()))
+            assert np.array_equal(outs[-1][0], mean) and np.array_equal(outs[-1][1], m2), (mode, eye, knob)
+            assert outs[-1][2] == orc.counters.as_dict(), (mode, eye, knob)
+            iv = tr.debug_invariants()
+            assert iv["violations"] == 0 and iv["samples_without_alpha_1"] == 0, iv
+            tr.close()
+            if knob is not None:
+                monkeypatch.delenv("CT_DELTA_INTERIOR")
+        assert outs[0][2] == outs[1][2] and outs[0][2]["scatter_events"] > 0
 
 
 def test_multi_gpu_step_on_the_rccl_backend_single_rank():

@@ -15,12 +15,16 @@ from test_gpu_parity import _random_scene, make_pair
 seed, cases = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
 bad = 0
+interior = delta_cases = 0   # DELTA cases, and those that ran the kernel without the box test and the clamp
 for case in range(cases):
     kw, eye = _random_scene(rng)
     tex = kw.pop("tex"); w, h = kw.pop("width"), kw.pop("height")
     # per-XCD job queues in a third of the cases (read at ct_create)
     os.environ["CT_XCD_QUEUES"] = "1" if rng.random() < 0.33 else "0"
     tr, orc = make_pair(tex, w, h, **kw)
+    if kw.get("estimator", 0) == 1:
+        delta_cases += 1
+        interior += 1 if tr.delta_grid()["interior"] else 0
     U, V, W = ds.calculate_camera_variables(eye, (0, 0, 0), (0, 1, 0), 30.0, w / h)
     tr.set_camera(eye, U, V, W); orc.set_camera(eye, U, V, W)
     first = 1
@@ -58,4 +62,4 @@ for case in range(cases):
     tr.close()
     if case % 50 == 49:
         print(f"{case + 1} cases, {bad} mismatches", flush=True)
-print(f"done: {cases} cases, {bad} mismatches")
+print(f"done: {cases} cases, {bad} mismatches ({delta_cases} with the DELTA estimator, {interior} of them on its interior kernel)")

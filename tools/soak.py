@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak run of the randomized differential test's generator: many random scenes and batch patterns, HIP path
-vs oracle, bit for bit.  python tools/soak.py <seed> <cases>"""
+vs oracle, bit for bit.  python tools/soak.py <seed> <cases>
+(SOAK_PAD=<texels>: every volume gets a zero border of that width; SOAK_EST=<0|1>: one estimator for every case)"""
 import os
 import sys
 from pathlib import Path
@@ -19,6 +20,10 @@ interior = delta_cases = 0   # DELTA cases, and those that ran the kernel withou
 for case in range(cases):
     kw, eye = _random_scene(rng)
     tex = kw.pop("tex"); w, h = kw.pop("width"), kw.pop("height")
+    if os.environ.get("SOAK_PAD"):      # a zero border of that many texels: the cloud inside its volume (the DELTA estimator's interior kernel)
+        tex = np.pad(tex, int(os.environ["SOAK_PAD"]))
+    if os.environ.get("SOAK_EST"):
+        kw["estimator"] = int(os.environ["SOAK_EST"])
     # per-XCD job queues in a third of the cases (read at ct_create)
     os.environ["CT_XCD_QUEUES"] = "1" if rng.random() < 0.33 else "0"
     tr, orc = make_pair(tex, w, h, **kw)

@@ -1053,6 +1053,13 @@ static int create_impl(const CtScene *s, CtHandle h)
             d.t_gx = (int32_t)tgx;
             d.t_gy = (int32_t)tgy;
             d.t_gz = (int32_t)tgz;
+            // (delta_interior's second half for this layout: the stored cells, grown by a texel, inside the TWIN grid)
+            const int32_t tg[3] = { d.t_gx, d.t_gy, d.t_gz }, o[3] = { d.mc_x0, d.mc_y0, d.mc_z0 }, st[3] = { d.mc_gx, d.mc_gy, d.mc_gz };
+            for (int a = 0; a < 3; a++) {
+                if (d.mc_cell * o[a] - bbias - 1 < -tbias || d.mc_cell * (o[a] + st[a]) - bbias > 3 * tg[a] - 1 - tbias) {
+                    d.delta_interior = 0u;
+                }
+            }
         }
         const hipError_t e2 = hipStreamSynchronize(h->stream);
         // Sparse storage (BASELINE.json configs[4]: "1024^3 sparse brick-compressed density"): CT_FLAG_SPARSE_BRICKS, or

@@ -428,6 +428,25 @@ CT_DEV size_t twin_offset_in_grid(const DevScene &sc, f3 p)
 #endif
     return ((size_t)brick << 7) | local;
 }
+// (without the clamp: DevScene::delta_interior, like apron_offset_unclamped)
+CT_DEV size_t twin_offset_unclamped(const DevScene &sc, f3 p)
+{
+    const float x = fmaf(p.x, sc.sx, -0.5f), y = fmaf(p.y, sc.sy, -0.5f), z = fmaf(p.z, sc.sz, -0.5f);
+    const uint32_t ux = (uint32_t)(floor_to_int(x) + sc.t_bias);
+    const uint32_t uy = (uint32_t)(floor_to_int(y) + sc.t_bias);
+    const uint32_t uz = (uint32_t)(floor_to_int(z) + sc.t_bias);
+    const uint32_t bx = __umul24(ux, 43691u) >> 17, by = __umul24(uy, 43691u) >> 17, bz = __umul24(uz, 43691u) >> 17; // u / 3, exact for u < 2^15
+    const uint32_t lx = ux - __umul24(bx, 3u), ly = uy - __umul24(by, 3u), lz = uz - __umul24(bz, 3u);
+    const uint32_t brick = __umul24(__umul24(bz, (uint32_t)sc.t_gy) + by, (uint32_t)sc.t_gx) + bx;
+    const uint32_t local = (lz << 4) + (ly << 2) + lx;
+#ifdef CT_DEBUG_BOUNDS
+    if (bx >= (uint32_t)sc.t_gx || by >= (uint32_t)sc.t_gy || bz >= (uint32_t)sc.t_gz) {
+        printf("CT_DEBUG_BOUNDS unclamped twin-brick texel (%u,%u,%u) outside the grid\n", ux, uy, uz);
+        return 0;
+    }
+#endif
+    return ((size_t)brick << 7) | local;
+}
 CT_DEV RawCell load_raw_twin(const uint8_t *q)
 {
     RawCell r;

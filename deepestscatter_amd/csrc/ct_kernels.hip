@@ -2063,7 +2063,7 @@ hipError_t launch_primary_advance_delta(const DevScene &sc, const float4 *primar
 //      hit on the line the density lookup has just brought, or that line's one fill when the lower bound made the lookup
 //      unnecessary.
 // INTERIOR: DevScene::delta_interior as a compile-time fact (the box test of a real collision and its three scene constants are
-// not in the kernel at all; as a run-time test it cost 3.4 %: the kernel spills scalar registers).  Instantiated for NEE = 1 only.
+// not in the kernel at all; as a run-time test it cost 3.4 %: the kernel spills scalar registers).  Instantiated for NEE = 1 and 2.
 template <int MODE, bool STATS, int NEE, bool INTERIOR = false>
 __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(CT_DELTA_WAVES))) void render_delta_kernel(DevScene sc, BatchArgs ba)
 {
@@ -2420,7 +2420,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                     if (NEE == 1) {
                         off = INTERIOR ? apron_offset_unclamped(sc, p) : apron_offset_in_grid(sc, p);
                     } else if (NEE == 2) {
-                        off = twin_offset_in_grid(sc, p);
+                        off = INTERIOR ? twin_offset_unclamped(sc, p) : twin_offset_in_grid(sc, p);
                     }
                     if (!real) {
                         uint2 cell;
@@ -2611,11 +2611,12 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
 template <bool STATS, int NEE>
 static void launch_render_delta_mode(const DevScene &sc, const BatchArgs &ba, dim3 grid, dim3 block, hipStream_t stream)
 {
-    if (NEE == 1 && !STATS && sc.delta_interior != 0u) {
+    if (NEE != 0 && !STATS && sc.delta_interior != 0u) {
+        constexpr int N = NEE != 0 ? NEE : 1;   // (NEE = 0, the round-3 layout kept for A/Bs, has no interior kernel)
         switch (sc.mode) {
-        case 0: hipLaunchKernelGGL((render_delta_kernel<0, false, 1, true>), grid, block, 0, stream, sc, ba); break;
-        case 1: hipLaunchKernelGGL((render_delta_kernel<1, false, 1, true>), grid, block, 0, stream, sc, ba); break;
-        default: hipLaunchKernelGGL((render_delta_kernel<2, false, 1, true>), grid, block, 0, stream, sc, ba); break;
+        case 0: hipLaunchKernelGGL((render_delta_kernel<0, false, N, true>), grid, block, 0, stream, sc, ba); break;
+        case 1: hipLaunchKernelGGL((render_delta_kernel<1, false, N, true>), grid, block, 0, stream, sc, ba); break;
+        default: hipLaunchKernelGGL((render_delta_kernel<2, false, N, true>), grid, block, 0, stream, sc, ba); break;
         }
         return;
     }

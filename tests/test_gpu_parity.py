@@ -1025,13 +1025,15 @@ def test_delta_fetch_layouts_against_the_oracle(nee, monkeypatch):
         tr.close()
 
 
-def test_delta_kernel_without_the_box_test_where_the_cloud_lies_inside_the_volume(monkeypatch):
+@pytest.mark.parametrize("nee", ["1", "2"])
+def test_delta_kernel_without_the_box_test_where_the_cloud_lies_inside_the_volume(monkeypatch, nee):
     """DevScene::delta_interior: when every non-zero texel lies two texels or more inside the volume's faces a REAL collision --
     a position with a non-zero footprint -- is inside the box, and render_delta_kernel<.., INTERIOR = true> (no isInBox after
     a real collision) runs.  The flag is set exactly at that margin; with it the results equal the oracle twin's (which always
     tests) bit for bit on a volume that is dense right up to the margin, seen from outside and from inside, in all three
     radiance programs; CT_DELTA_INTERIOR=0 runs the kernel with the test and gives the same."""
     monkeypatch.setenv("CT_DEBUG_INVARIANTS", "1")
+    monkeypatch.setenv("CT_DELTA_NEE", nee)   # (apron bricks with the shadow footprint requested at the collision / twin bricks)
     rng = np.random.default_rng(23)
 
     def slab(n, lo, hi):
@@ -1042,7 +1044,7 @@ def test_delta_kernel_without_the_box_test_where_the_cloud_lies_inside_the_volum
     for tex, want in ((slab(28, 6, 21), True), (slab(28, 1, 21), False), (slab(28, 6, 26), False), (rng.integers(0, 256, (14, 19, 26)).astype(np.uint8), False),
                       (sphere_volume(44, radius=0.38, seed=41), True)):
         tr = ds.CloudTracer(tex, width=16, height=16, estimator=1)
-        assert tr.delta_grid()["interior"] is want and tr.delta_grid()["nee"] == 1
+        assert tr.delta_grid()["interior"] is want and tr.delta_grid()["nee"] == int(nee)
         tr.close()
     for tex, mode, eye in [(slab(28, 6, 21), m, e) for m in (0, 1, 2) for e in ((0.3, 0.25, 3.0), (0.05, 0.02, 0.1))] + \
                           [(slab(20, 2, 17), 0, (0.3, 0.25, 3.0)), (slab(24, 3, 20), 0, (-2.0, 0.4, 0.3))]:   # (at and near the margin: whichever kernel runs)

@@ -1167,7 +1167,9 @@ hipError_t launch_primary_advance(const DevScene &sc, const float4 *primary, flo
 // the list of this shard's box-hitting pixels (tile-Morton order).  See BatchArgs for the order.
 // (6 waves per SIMD = 3 blocks of 512 threads per CU: the register allocator must stay within 80 VGPRs.  It
 // uses 75 today; an edit of take_job once moved it to 85 and cost a third of the occupancy, hence the bound.)
-template <int MODE, bool STATS, bool SPARSE>
+// COST = false: a launch that does not record the paths' costs (BatchArgs::cost is null: every launch but the one that measures
+// them) runs the kernel compiled without the per-path work counter.  Instantiated for the dense, non-diagnostic kernel.
+template <int MODE, bool STATS, bool SPARSE, bool COST = true>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void render_persistent_kernel(DevScene sc, BatchArgs ba)
 {
     __shared__ MieLdsFull lds;
@@ -1424,7 +1426,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                         }
                     }
                     c_il += 1;
-                    work += 4u;
+                    if (COST) {
+                        work += 4u;
+                    }
                     bool go = (MODE != 2);
                     if (go) {
                         dir = new_direction(lds.cdf, lds.guide, seed, dir);
@@ -1501,7 +1505,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 const uint2 cell = fetch_cell_m<SPARSE>(sc, pos, meta);
                 dfree = meta & 0x7fu;
                 c_dl += 1;
-                work += 1u;
+                if (COST) {
+                    work += 1u;
+                }
                 if (STATS) {
                     st_fetch += 1;
                     // (round-3 question: would a brick cache in LDS find anything?  The 128-B line of this footprint against
@@ -1556,7 +1562,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                     if (STATS) {
                         iv_written += 1;
                     }
-                    if (ba.cost) {
+                    if (COST && ba.cost) {
                         ba.cost[out_idx - ba.out_offset] = make_uint2(work, depth);
                     }
                     state = ST_IDLE;
@@ -1590,7 +1596,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             if (STATS) {
                 iv_written += 1;
             }
-            if (ba.cost) {
+            if (COST && ba.cost) {
                 ba.cost[out_idx - ba.out_offset] = make_uint2(work, depth);
             }
             state = ST_IDLE;
@@ -2683,6 +2689,14 @@ LaunchShape persistent_shape(int device, bool delta, int blocks_per_cu)
 template <bool STATS, bool SPARSE>
 static void launch_render_persistent_mode(const DevScene &sc, const BatchArgs &ba, dim3 grid, dim3 block, hipStream_t stream)
 {
+    if (!STATS && !SPARSE && ba.cost == nullptr) {
+        switch (sc.mode) {
+        case 0: hipLaunchKernelGGL((render_persistent_kernel<0, false, false, false>), grid, block, 0, stream, sc, ba); break;
+        case 1: hipLaunchKernelGGL((render_persistent_kernel<1, false, false, false>), grid, block, 0, stream, sc, ba); break;
+        default: hipLaunchKernelGGL((render_persistent_kernel<2, false, false, false>), grid, block, 0, stream, sc, ba); break;
+        }
+        return;
+    }
     switch (sc.mode) {
     case 0: hipLaunchKernelGGL((render_persistent_kernel<0, STATS, SPARSE>), grid, block, 0, stream, sc, ba); break;
     case 1: hipLaunchKernelGGL((render_persistent_kernel<1, STATS, SPARSE>), grid, block, 0, stream, sc, ba); break;

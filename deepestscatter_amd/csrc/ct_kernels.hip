@@ -2264,7 +2264,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                                 if (STATS) {
                                     iv_written += 1;
                                 }
-                                if (ba.cost) {
+                                if (!INTERIOR && ba.cost) {   // (the interior kernel serves the launches that record no path costs)
                                     ba.cost[out_idx - ba.out_offset] = make_uint2(depth, depth);
                                 }
                             } else {
@@ -2478,7 +2478,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
                     if (STATS) {
                         iv_written += 1;
                     }
-                    if (ba.cost) {
+                    if (!INTERIOR && ba.cost) {   // (the interior kernel serves the launches that record no path costs)
                         ba.cost[out_idx - ba.out_offset] = make_uint2(depth, depth);
                     }
                     state = ST_IDLE;
@@ -2520,7 +2520,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
             if (STATS) {
                 iv_written += 1;
             }
-            if (ba.cost) {
+            if (!INTERIOR && ba.cost) {   // (the interior kernel serves the launches that record no path costs)
                 ba.cost[out_idx - ba.out_offset] = make_uint2(depth, depth);
             }
             state = ST_IDLE;
@@ -2617,7 +2617,7 @@ __global__ __launch_bounds__(kDeltaThreads) __attribute__((amdgpu_waves_per_eu(C
 template <bool STATS, int NEE>
 static void launch_render_delta_mode(const DevScene &sc, const BatchArgs &ba, dim3 grid, dim3 block, hipStream_t stream)
 {
-    if (NEE != 0 && !STATS && sc.delta_interior != 0u) {
+    if (NEE != 0 && !STATS && sc.delta_interior != 0u && ba.cost == nullptr) {   // (the launch that measures path costs: the general kernel)
         constexpr int N = NEE != 0 ? NEE : 1;   // (NEE = 0, the round-3 layout kept for A/Bs, has no interior kernel)
         switch (sc.mode) {
         case 0: hipLaunchKernelGGL((render_delta_kernel<0, false, N, true>), grid, block, 0, stream, sc, ba); break;

@@ -1206,6 +1206,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
     // scheduler diagnostics (STATS builds only), see ct_debug_stats
     uint32_t st_regen = 0, st_regen_l = 0, st_march = 0, st_march_l = 0, st_scat = 0, st_scat_l = 0;
     uint32_t st_fetch = 0, st_zero = 0, st_skip = 0, st_zero_d0 = 0, st_zero_d1 = 0, st_skip_iters = 0, st_stolen = 0, st_iters = 0, st_first = 0;
+    uint32_t st_hit2 = 0, st_hit3 = 0, st_h2 = 0xffffffffu, st_h3 = 0xffffffffu;   // (diagnostics: a deeper footprint cache)
     uint32_t st_same_line = 0, st_dup_line = 0, st_prev_line = 0xffffffffu;   // brick-line reuse of the march fetches (STATS)
 
     // ---------------- resume the paths the previous launch suspended ----------------
@@ -1416,7 +1417,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
                 if (dfree != 0u || in_box(sc, pos)) {
                     const bool chopped = (MODE == 1) ? true : (MODE == 0 ? (depth != 1) : false);
                     bool nee_reused;
+                    const uint32_t st_key_before = nee_key;
                     const NeeLoads nee = in_scattering_issue_lds(sc, lds.chopped, pos, dir, chopped, nee_key, nee_cell, nee_reused);
+                    if (STATS && !nee_reused) {
+                        // (would a second / third entry -- the footprints before the one just replaced -- have held this one?)
+                        st_hit2 += (nee_key == st_h2) ? 1u : 0u;
+                        st_hit3 += (nee_key != st_h2 && nee_key == st_h3) ? 1u : 0u;
+                        st_h3 = st_h2;
+                        st_h2 = st_key_before;
+                    }
                     nee_fetched = !nee_reused;
                     if (STATS) {
                         st_first += nee_reused ? 1u : 0u;
@@ -1652,10 +1661,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
         vals[i] = v;
     }
     if (STATS) {
-        uint32_t sv[13] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1, st_skip_iters, st_first,
-                            iv_dealt, iv_resumed, iv_written, iv_suspended, st_same_line, st_dup_line };
+        uint32_t sv[15] = { st_fetch, st_zero, st_skip, st_zero_d0, st_zero_d1, st_skip_iters, st_first,
+                            iv_dealt, iv_resumed, iv_written, iv_suspended, st_same_line, st_dup_line, st_hit2, st_hit3 };
 #pragma unroll
-        for (int i = 0; i < 13; i++) {
+        for (int i = 0; i < 15; i++) {
             uint32_t v = sv[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -1694,6 +1703,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void r
             atomicAdd(&ba.stats[67], (unsigned long long)sv[10]);
             atomicAdd(&ba.stats[68], (unsigned long long)sv[11]);
             atomicAdd(&ba.stats[69], (unsigned long long)sv[12]);
+            atomicAdd(&ba.stats[70], (unsigned long long)sv[13]);
+            atomicAdd(&ba.stats[71], (unsigned long long)sv[14]);
         }
     }
     if (lane == 0) {
